@@ -1,0 +1,110 @@
+"""Loader of the C-ABI library ``libcednerf_hip.so`` (declared in ``include/cednerf_hip.h``).
+
+There is deliberately no CPU or PyTorch fallback: if the library is missing or fails to load,
+``lib()`` raises and every op of this package fails loudly.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import subprocess
+from typing import List, Optional
+
+_PKG = os.path.dirname(os.path.abspath(__file__))
+_ROOT = os.path.dirname(_PKG)
+LIB_PATH = os.path.join(_PKG, "libcednerf_hip.so")
+SOURCES = ["runtime.hip", "march.hip", "composite.hip", "field.hip"]
+HIPCC_FLAGS = ["--offload-arch=gfx950", "-O3", "-ffp-contract=off", "-fPIC", "-shared", "-std=c++17"]
+MAX_LEVELS = 16
+
+
+class HashDesc(C.Structure):
+    """ced_hash_desc"""
+    _fields_ = [
+        ("n_levels", C.c_int32), ("table_dtype", C.c_int32), ("temporal", C.c_int32), ("reserved", C.c_int32),
+        ("scale", C.c_float * MAX_LEVELS), ("res", C.c_uint32 * MAX_LEVELS), ("offset", C.c_uint32 * MAX_LEVELS),
+        ("size", C.c_uint32 * MAX_LEVELS), ("hashed", C.c_uint32 * MAX_LEVELS),
+        ("table", C.c_void_p), ("total_entries", C.c_uint64),
+    ]
+
+
+class FieldDesc(C.Structure):
+    """ced_field_desc"""
+    _fields_ = [
+        ("aabb", C.c_float * 6), ("moving_step", C.c_float), ("use_div_offsets", C.c_int32),
+        ("time_mode", C.c_int32), ("reserved", C.c_int32),
+        ("packed_weights", C.c_void_p), ("packed_floats", C.c_uint64),
+        ("hash", HashDesc),
+    ]
+
+
+_vp, _i64, _i32, _f = C.c_void_p, C.c_int64, C.c_int32, C.c_float
+
+# name -> (restype, argtypes); one entry per function declared in include/cednerf_hip.h
+PROTOTYPES = {
+    "ced_version": (C.c_int, []),
+    "ced_last_error_string": (C.c_char_p, []),
+    "ced_packed_weight_floats": (_i64, [C.c_int, C.c_int]),
+    "ced_pack_field_weights": (C.c_int, [C.c_int, C.c_int] + [_vp] * 10),
+    "ced_ray_aabb_intersect": (C.c_int, [_i64, _vp, _vp, _i32, _vp, _f, _f, _f, _vp, _vp, _vp, _vp]),
+    "ced_traverse_grids": (C.c_int, [_i64, _vp, _vp, _vp, _i32, _i32, _vp, _vp, _vp, _f, _f, _i32, _vp, _vp, _vp, _vp,
+                                     _i32, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "ced_hash_encode": (C.c_int, [C.POINTER(HashDesc), _i64, _vp, _vp, _vp, _vp]),
+    "ced_field_forward": (C.c_int, [C.POINTER(FieldDesc), _i64, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "ced_field_forward_rays": (C.c_int, [C.POINTER(FieldDesc), _i64, _vp, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _vp,
+                                         _vp, _vp]),
+    "ced_render_weights": (C.c_int, [_i64, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "ced_accumulate_along_rays": (C.c_int, [_i64, _vp, _vp, _vp, _i32, _vp, _vp]),
+    "ced_visibility_mask": (C.c_int, [_i64, _vp, _vp, _vp, _vp, _f, _f, _vp, _vp]),
+    "ced_composite_prefix": (C.c_int, [_i64, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "ced_composite_test": (C.c_int, [_i64, _vp, _vp, _vp, _vp, _vp, _vp, _f, _f, _vp, _vp, _vp, _vp]),
+    "ced_finalize_pixels": (C.c_int, [_i64, _vp, _vp, _vp, _vp, _vp]),
+}
+
+
+def build(force: bool = False, verbose: bool = False) -> str:
+    """Compile every HIP source for gfx950 into the in-tree shared library (hipcc cross-compiles
+    without a GPU)."""
+    srcs = [os.path.join(_PKG, "csrc", s) for s in SOURCES]
+    deps = srcs + [os.path.join(_PKG, "csrc", "ced_common.hpp"), os.path.join(_ROOT, "include", "cednerf_hip.h")]
+    if not force and os.path.exists(LIB_PATH) and all(os.path.getmtime(LIB_PATH) >= os.path.getmtime(d) for d in deps):
+        return LIB_PATH
+    hipcc = os.environ.get("HIPCC", "hipcc")
+    cmd = [hipcc] + HIPCC_FLAGS + ["-o", LIB_PATH] + srcs
+    if verbose:
+        print(" ".join(cmd))
+    subprocess.check_call(cmd)
+    return LIB_PATH
+
+
+_lib: Optional[C.CDLL] = None
+
+
+def lib() -> C.CDLL:
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise RuntimeError(
+                f"{LIB_PATH} not found: build the HIP extension first (python -c 'import __graft_entry__ as g; "
+                "g.build()'); ced_nerf_amd has no CPU fallback")
+        handle = C.CDLL(LIB_PATH)
+        for name, (res, args) in PROTOTYPES.items():
+            fn = getattr(handle, name)      # AttributeError if the library lacks a declared symbol
+            fn.restype = res
+            fn.argtypes = args
+        _lib = handle
+    return _lib
+
+
+def check(rc: int, what: str = "") -> None:
+    if rc != 0:
+        msg = lib().ced_last_error_string()
+        raise RuntimeError(f"libcednerf_hip {what} failed (code {rc}): {msg.decode() if msg else ''}")
+
+
+def header_symbols() -> List[str]:
+    """Function names declared in include/cednerf_hip.h (used by the CPU test-suite)."""
+    import re
+    text = open(os.path.join(_ROOT, "include", "cednerf_hip.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(ced_[a-z0-9_]+)\s*\(", text)))

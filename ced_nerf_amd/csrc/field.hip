@@ -1,0 +1,667 @@
+// Fused dynamic-NGP radiance field for gfx950: Frequency encoding -> motion MLP -> normalise /
+// selector -> multi-resolution hash gather -> [time encoding] -> mlp_base -> trunc_exp ->
+// SH(2) -> mlp_head -> sigmoid, one kernel, nothing but the inputs and (rgb, sigma) touch HBM.
+// Replaces DNGPradianceField.forward (cednerf/model.py:468-488; query_move :354-365,
+// query_density :367-445, _query_rgb :447-466), i.e. five tiny-cuda-nn launches plus ~12 torch
+// glue kernels per call, and the sigma_fn / rgb_sigma_fn closures of cednerf/utils.py:74-104,181-195.
+//
+// Execution shape (CDNA4): one 512-thread workgroup per CU (2 waves per SIMD), persistent over
+// 64-sample wave tiles.  All nine weight matrices (~86 KB fp32, pre-swizzled by the host into
+// MFMA A-fragment order) are staged into LDS once per workgroup and read with conflict-free
+// ds_read_b128.  The GEMMs run on v_mfma_f32_16x16x4_f32 with D^T = W * X^T (neurons on the
+// accumulator rows, samples on lanes): exact fp32, an ascending-k fused-multiply-add chain,
+// which is what makes sample counts downstream bit-exact against the CPU oracle.  Activations
+// never leave registers: a layer's 16x16 accumulator block becomes the next layer's B operand
+// through a 4x4 lane-group <-> register transpose (2x v_permlane32_swap + 2x v_permlane16_swap).
+// The hash gather is laid out in the same fragment geometry: lane group g owns levels
+// {2g, 2g+1, 8+2g, 9+2g} of its 16 samples, so the gathered features land in B-operand order
+// after two such transposes and the 128 gathers per sample are spread over 4 lanes.
+#include "ced_common.hpp"
+
+namespace ced {
+
+typedef float f4 __attribute__((ext_vector_type(4)));
+
+constexpr int NT = 4;         // 16-sample MFMA column tiles per wave iteration (64 samples)
+constexpr int FIELD_THREADS = 512;
+constexpr int FIELD_WAVES = FIELD_THREADS / kWave;
+
+// ---- packed weight blob: layer l stored as [nb][ks4][lane 64][4] floats ----------------------
+struct LayerShape { int nb; int ks; };
+__host__ __device__ constexpr int ks4_of(int ks) { return (ks + 3) / 4; }
+__host__ __device__ constexpr int layer_floats(int nb, int ks) { return nb * ks4_of(ks) * 256; }
+
+template <bool TE> struct Blob {
+    static constexpr int KS_B0 = TE ? 11 : 8;
+    static constexpr int M0 = 0;
+    static constexpr int M1 = M0 + layer_floats(4, 8);
+    static constexpr int M2 = M1 + layer_floats(4, 16);
+    static constexpr int M3 = M2 + layer_floats(4, 16);
+    static constexpr int B0 = M3 + layer_floats(1, 16);
+    static constexpr int B1 = B0 + layer_floats(4, KS_B0);
+    static constexpr int H0 = B1 + layer_floats(1, 16);
+    static constexpr int H1 = H0 + layer_floats(4, 5);
+    static constexpr int H2 = H1 + layer_floats(4, 16);
+    static constexpr int TOTAL = H2 + layer_floats(1, 16);
+};
+constexpr int kMaxBlobFloats = Blob<true>::TOTAL;
+
+struct FieldArgs {
+    int64_t n;
+    const float *pos, *t, *dir;                       // explicit mode
+    const float *rays_o, *rays_d;                     // rays mode
+    const int64_t *ray_idx;
+    const float *t0, *t1, *timestamps;
+    int rays_mode, t_per_ray, want_rgb;
+    float *rgb, *sigma, *geo;
+    float aabb[6];
+    float moving_step;
+    int use_div, time_mode;
+    const float *weights;
+    int table_dtype, temporal;
+    const void *table;
+    float scale[CED_MAX_LEVELS];
+    uint32_t res[CED_MAX_LEVELS], offset[CED_MAX_LEVELS], size[CED_MAX_LEVELS], hashed[CED_MAX_LEVELS];
+};
+
+// ---- 4x4 transpose between the wave's four 16-lane groups and four registers ------------------
+// out reg s on lane group q  =  in reg q on lane group s
+__device__ __forceinline__ void transpose4(float &r0, float &r1, float &r2, float &r3)
+{
+    auto a = __builtin_amdgcn_permlane32_swap(__float_as_uint(r0), __float_as_uint(r2), false, false);
+    auto b = __builtin_amdgcn_permlane32_swap(__float_as_uint(r1), __float_as_uint(r3), false, false);
+    auto c = __builtin_amdgcn_permlane16_swap(a[0], b[0], false, false);
+    auto d = __builtin_amdgcn_permlane16_swap(a[1], b[1], false, false);
+    r0 = __uint_as_float(c[0]);
+    r1 = __uint_as_float(c[1]);
+    r2 = __uint_as_float(d[0]);
+    r3 = __uint_as_float(d[1]);
+}
+
+// D[j][nb] (16 neurons x 16 samples, neurons 16nb+4g+r on lane group g reg r) =
+//     sum_k W[neuron][k] * B[j][k/4] (k = 4S+g on lane group g), ascending k.
+template <int KS, int NB>
+__device__ __forceinline__ void mlp_layer(const float *__restrict__ wl, int lane, const float (&B)[NT][16],
+                                          f4 (&D)[NT][4])
+{
+    constexpr int KS4 = ks4_of(KS);
+#pragma unroll
+    for (int nb = 0; nb < NB; ++nb) {
+        f4 acc[NT];
+#pragma unroll
+        for (int j = 0; j < NT; ++j) acc[j] = f4{ 0.0f, 0.0f, 0.0f, 0.0f };
+#pragma unroll
+        for (int q = 0; q < KS4; ++q) {
+            const f4 a = *reinterpret_cast<const f4 *>(wl + ((nb * KS4 + q) * 64 + lane) * 4);
+#pragma unroll
+            for (int s = 0; s < 4; ++s) {
+                if (4 * q + s < KS) {
+#pragma unroll
+                    for (int j = 0; j < NT; ++j)
+                        acc[j] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[s], B[j][4 * q + s], acc[j], 0, 0, 0);
+                }
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < NT; ++j) D[j][nb] = acc[j];
+    }
+}
+
+// ReLU (optional) on the accumulator blocks, then transpose them into the next layer's B operand.
+template <int NB, bool RELU>
+__device__ __forceinline__ void to_operand(const f4 (&D)[NT][4], float (&B)[NT][16])
+{
+#pragma unroll
+    for (int j = 0; j < NT; ++j) {
+#pragma unroll
+        for (int nb = 0; nb < NB; ++nb) {
+            float r[4];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                float v = D[j][nb][q];
+                r[q] = RELU ? ((v > 0.0f) ? v : 0.0f) : v;
+            }
+            transpose4(r[0], r[1], r[2], r[3]);
+#pragma unroll
+            for (int s = 0; s < 4; ++s) B[j][4 * nb + s] = r[s];
+        }
+    }
+}
+
+struct LevelConst {
+    float scale;
+    uint32_t sy, sz;       // per-axis multipliers: primes when hashed, (res, res^2) when dense
+    uint32_t offset, size, hashed;
+};
+
+// Trilinear gather of one level for one point (hash_encoder_half.py:112-161; temporal variant
+// hash_encoder_inter.py:148-197).  x already clamped to [0,1].
+__device__ __forceinline__ void hash_level(const LevelConst &L, const void *__restrict__ table, int table_dtype,
+                                           int temporal, const float (&x)[3], int k_lo, float t_frac, float &f0,
+                                           float &f1)
+{
+    uint32_t g[3];
+    float fr[3], om[3];
+#pragma unroll
+    for (int a = 0; a < 3; ++a) {
+        float p = x[a] * L.scale + 0.5f;
+        float fl = __builtin_floorf(p);
+        g[a] = (uint32_t)fl;
+        fr[a] = p - fl;
+        om[a] = 1.0f - fr[a];
+    }
+    const uint32_t xs[2] = { g[0], g[0] + 1u };
+    const uint32_t ys[2] = { g[1] * L.sy, (g[1] + 1u) * L.sy };
+    const uint32_t zs[2] = { g[2] * L.sz, (g[2] + 1u) * L.sz };
+    const bool hashed = L.hashed != 0;
+    const uint32_t mask = L.size - 1u;
+    uint32_t e[8];
+    float w[8];
+#pragma unroll
+    for (int c = 0; c < 8; ++c) {
+        const int cx = c & 1, cy = (c >> 1) & 1, cz = (c >> 2) & 1;
+        uint32_t hx = xs[cx] ^ ys[cy] ^ zs[cz];
+        uint32_t dx = xs[cx] + ys[cy] + zs[cz];
+        uint32_t dm = (dx >= L.size) ? dx - L.size : dx;
+        e[c] = L.offset + (hashed ? (hx & mask) : dm);
+        float wx = cx ? fr[0] : om[0];
+        float wy = cy ? fr[1] : om[1];
+        float wz = cz ? fr[2] : om[2];
+        w[c] = (wx * wy) * wz;
+    }
+    float v0[8], v1[8];
+    if (!temporal) {
+        if (table_dtype == 0) {
+            const float2 *tb = reinterpret_cast<const float2 *>(table);
+#pragma unroll
+            for (int c = 0; c < 8; ++c) { float2 v = tb[e[c]]; v0[c] = v.x; v1[c] = v.y; }
+        } else {
+            const uint32_t *tb = reinterpret_cast<const uint32_t *>(table);
+#pragma unroll
+            for (int c = 0; c < 8; ++c) {
+                uint32_t v = tb[e[c]];
+                v0[c] = half_bits_to_float((uint16_t)(v & 0xffffu));
+                v1[c] = half_bits_to_float((uint16_t)(v >> 16));
+            }
+        }
+    } else {
+        const float omt = 1.0f - t_frac;
+        if (table_dtype == 0) {
+            const float2 *tb = reinterpret_cast<const float2 *>(table);
+#pragma unroll
+            for (int c = 0; c < 8; ++c) {
+                float2 lo = tb[(uint64_t)e[c] * 4u + k_lo], hi = tb[(uint64_t)e[c] * 4u + k_lo + 1];
+                v0[c] = lo.x * omt + hi.x * t_frac;
+                v1[c] = lo.y * omt + hi.y * t_frac;
+            }
+        } else {
+            const uint32_t *tb = reinterpret_cast<const uint32_t *>(table);
+#pragma unroll
+            for (int c = 0; c < 8; ++c) {
+                uint32_t lo = tb[(uint64_t)e[c] * 4u + k_lo], hi = tb[(uint64_t)e[c] * 4u + k_lo + 1];
+                float a0 = half_bits_to_float((uint16_t)(lo & 0xffffu)), a1 = half_bits_to_float((uint16_t)(lo >> 16));
+                float b0 = half_bits_to_float((uint16_t)(hi & 0xffffu)), b1 = half_bits_to_float((uint16_t)(hi >> 16));
+                v0[c] = a0 * omt + b0 * t_frac;
+                v1[c] = a1 * omt + b1 * t_frac;
+            }
+        }
+    }
+    float acc0 = 0.0f, acc1 = 0.0f;
+#pragma unroll
+    for (int c = 0; c < 8; ++c) {
+        acc0 = __builtin_fmaf(w[c], v0[c], acc0);
+        acc1 = __builtin_fmaf(w[c], v1[c], acc1);
+    }
+    f0 = acc0;
+    f1 = acc1;
+}
+
+__device__ __forceinline__ void temporal_keyframe(float tq, int &k_lo, float &t_frac)
+{
+    float ts = tq * 3.0f;
+    float fl = __builtin_floorf(ts);
+    t_frac = ts - fl;
+    fl = __builtin_fminf(fl, 2.0f);
+    k_lo = (int)fl;
+}
+
+// feature idx (0..8, >8 -> 0) of the 9-wide time encoding (cednerf/encoder.py:6-44 / :46-90)
+__device__ __forceinline__ float time_feature(int idx, int time_mode, float t, float mn)
+{
+    const float HALF_PI = 1.57079637050628662f;
+    if (idx == 0) return t;
+    if (idx > 8) return 0.0f;
+    int k, ph;
+    if (time_mode == 1) { k = (idx - 1) & 3; ph = (idx - 1) >> 2; }
+    else { k = (idx - 1) >> 1; ph = (idx - 1) & 1; }
+    float xb = t * (float)(1 << k);
+    float arg = ph ? (xb + HALF_PI) : xb;
+    float s = det_sinf(arg);
+    if (time_mode == 2) {
+        float att = det_expf(-1.0f * (mn * (float)(k * (1 << k))));
+        s = s * att;
+    }
+    return s;
+}
+
+template <bool TE>
+__global__ __launch_bounds__(FIELD_THREADS, 2) void field_kernel(FieldArgs A)
+{
+    using BL = Blob<TE>;
+    __shared__ __attribute__((aligned(16))) float lds[BL::TOTAL + 8 * CED_MAX_LEVELS];
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = tid >> 6;
+    const int g = lane >> 4, c = lane & 15;
+
+    // stage weights + level tables into LDS
+    {
+        const f4 *src = reinterpret_cast<const f4 *>(A.weights);
+        f4 *dst = reinterpret_cast<f4 *>(lds);
+        for (int i = tid; i < BL::TOTAL / 4; i += FIELD_THREADS) dst[i] = src[i];
+        if (tid < CED_MAX_LEVELS) {
+            uint32_t *lt = reinterpret_cast<uint32_t *>(lds + BL::TOTAL);
+            const bool hs = A.hashed[tid] != 0;
+            lt[tid * 8 + 0] = __float_as_uint(A.scale[tid]);
+            lt[tid * 8 + 1] = hs ? 2654435761u : A.res[tid];
+            lt[tid * 8 + 2] = hs ? 805459861u : A.res[tid] * A.res[tid];
+            lt[tid * 8 + 3] = A.offset[tid];
+            lt[tid * 8 + 4] = A.size[tid];
+            lt[tid * 8 + 5] = A.hashed[tid];
+        }
+    }
+    __syncthreads();
+
+    // the four levels this lane group gathers: {2g, 2g+1, 8+2g, 9+2g}
+    LevelConst LC[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int lvl = (i < 2) ? (2 * g + i) : (8 + 2 * g + (i - 2));
+        const uint32_t *lt = reinterpret_cast<const uint32_t *>(lds + BL::TOTAL) + lvl * 8;
+        LC[i].scale = __uint_as_float(lt[0]);
+        LC[i].sy = lt[1];
+        LC[i].sz = lt[2];
+        LC[i].offset = lt[3];
+        LC[i].size = lt[4];
+        LC[i].hashed = lt[5];
+    }
+
+    const int64_t n_tiles = (A.n + 63) / 64;
+    const float extent[3] = { A.aabb[3] - A.aabb[0], A.aabb[4] - A.aabb[1], A.aabb[5] - A.aabb[2] };
+
+    for (int64_t tile = (int64_t)blockIdx.x * FIELD_WAVES + wave; tile < n_tiles;
+         tile += (int64_t)gridDim.x * FIELD_WAVES) {
+        int64_t sidx[NT];
+        int64_t ridx[NT];
+        float px[NT][3], tq[NT];
+#pragma unroll
+        for (int j = 0; j < NT; ++j) {
+            int64_t s = tile * 64 + 16 * j + c;
+            s = s < A.n ? s : A.n - 1;
+            sidx[j] = s;
+            if (A.rays_mode) {
+                const int64_t r = A.ray_idx[s];
+                ridx[j] = r;
+                const float tm2 = A.t0[s] + A.t1[s];
+#pragma unroll
+                for (int a = 0; a < 3; ++a) px[j][a] = A.rays_o[3 * r + a] + (A.rays_d[3 * r + a] * tm2) / 2.0f;
+                tq[j] = A.t_per_ray ? A.timestamps[r] : A.timestamps[0];
+            } else {
+                ridx[j] = s;
+#pragma unroll
+                for (int a = 0; a < 3; ++a) px[j][a] = A.pos[3 * s + a];
+                tq[j] = A.t[s];
+            }
+        }
+
+        float B[NT][16];
+        f4 D[NT][4];
+
+        // --- tcnn Frequency(4) on (x,y,z,t): feature k = 8*dim + 2*freq + phase, k = 4S+g ---
+#pragma unroll
+        for (int j = 0; j < NT; ++j) {
+#pragma unroll
+            for (int S = 0; S < 8; ++S) {
+                const int dim = S >> 1;
+                const float v = (dim < 3) ? px[j][dim < 3 ? dim : 0] : tq[j];
+                const int f = 2 * (S & 1) + (g >> 1);
+                const float y = v * (float)(1 << f);
+                B[j][S] = det_sinpi_phase(y, g & 1);
+            }
+        }
+        // --- motion MLP 32-64-64-64-(3|6) ---
+        mlp_layer<8, 4>(lds + BL::M0, lane, B, D);
+        to_operand<4, true>(D, B);
+        mlp_layer<16, 4>(lds + BL::M1, lane, B, D);
+        to_operand<4, true>(D, B);
+        mlp_layer<16, 4>(lds + BL::M2, lane, B, D);
+        to_operand<4, true>(D, B);
+        mlp_layer<16, 1>(lds + BL::M3, lane, B, D);
+
+        // --- query_move / normalise / selector (model.py:354-383) ---
+        float xn[NT][3], mnorm[NT];
+        bool sel[NT];
+#pragma unroll
+        for (int j = 0; j < NT; ++j) {
+            float mv[3];
+            bool inside = true;
+#pragma unroll
+            for (int a = 0; a < 3; ++a) {
+                const float off = __shfl(D[j][0][a], c, 64);          // row a lives on lane group 0, reg a
+                float m = off * A.moving_step;
+                if (A.use_div) {
+                    // rows 3,4,5: (g0,r3), (g1,r0), (g1,r1)
+                    constexpr int kFineReg[3] = { 3, 0, 1 };
+                    const float fine = __shfl(D[j][0][kFineReg[a]], (a == 0) ? c : 16 + c, 64);
+                    const float e = det_expf(2.0f * fine);
+                    const float th = 1.0f - 2.0f / (e + 1.0f);
+                    m = m + th * A.moving_step;
+                }
+                mv[a] = m;
+                const float xm = px[j][a] + m;
+                const float x = (xm - A.aabb[a]) / extent[a];
+                inside = inside && (x > 0.0f && x < 1.0f);
+                xn[j][a] = __builtin_fminf(__builtin_fmaxf(x, 0.0f), 1.0f);
+            }
+            sel[j] = inside;
+            mnorm[j] = TE ? __builtin_sqrtf((mv[0] * mv[0] + mv[1] * mv[1]) + mv[2] * mv[2]) : 0.0f;
+        }
+
+        // --- hash gather: this lane's 4 levels for each of its 4 samples, then into operand order ---
+#pragma unroll
+        for (int j = 0; j < NT; ++j) {
+            int k_lo = 0;
+            float t_frac = 0.0f;
+            if (A.temporal) temporal_keyframe(tq[j], k_lo, t_frac);
+            float R[8];
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+                hash_level(LC[i], A.table, A.table_dtype, A.temporal, xn[j], k_lo, t_frac, R[2 * i], R[2 * i + 1]);
+            transpose4(R[0], R[1], R[2], R[3]);
+            transpose4(R[4], R[5], R[6], R[7]);
+#pragma unroll
+            for (int s = 0; s < 8; ++s) B[j][s] = R[s];
+            if (TE) {
+#pragma unroll
+                for (int S = 8; S < 11; ++S) B[j][S] = time_feature(4 * (S - 8) + g, A.time_mode, tq[j], mnorm[j]);
+            }
+        }
+
+        // --- mlp_base (32|41)-64-16; accumulator row p holds output neuron (p+13)&15 ---
+        mlp_layer<BL::KS_B0, 4>(lds + BL::B0, lane, B, D);
+        to_operand<4, true>(D, B);
+        mlp_layer<16, 1>(lds + BL::B1, lane, B, D);
+
+        const bool store_lane = (g == 0);
+#pragma unroll
+        for (int j = 0; j < NT; ++j) {
+            const int64_t s = tile * 64 + 16 * j + c;
+            float sg = det_expf(D[j][0][3] - 1.0f);           // density = trunc_exp(raw - 1) * selector
+            sg = sel[j] ? sg : 0.0f;
+            if (store_lane && s < A.n) A.sigma[s] = sg;
+            if (A.geo && s < A.n) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int nidx = (4 * g + r + 13) & 15;
+                    if (nidx >= 1) A.geo[s * 15 + nidx - 1] = D[j][0][r];
+                }
+            }
+        }
+
+        if (A.want_rgb) {
+            // --- head input: [SH(4), geo(15)] (model.py:447-459); k = 4S+g ---
+            to_operand<1, false>(D, B);      // B[j][0..3] = accumulator rows 4s+g
+#pragma unroll
+            for (int j = 0; j < NT; ++j) {
+                const float geo_tail = (g == 3) ? 0.0f : B[j][0];     // rows 0,1,2 = neurons 13,14,15; row 3 = density
+                float dv[3];
+#pragma unroll
+                for (int a = 0; a < 3; ++a)
+                    dv[a] = A.rays_mode ? A.rays_d[3 * ridx[j] + a] : A.dir[3 * sidx[j] + a];
+                const float nrm = __builtin_sqrtf((dv[0] * dv[0] + dv[1] * dv[1]) + dv[2] * dv[2]);
+                float v[3];
+#pragma unroll
+                for (int a = 0; a < 3; ++a) {
+                    const float u = (dv[a] / nrm + 1.0f) / 2.0f;
+                    v[a] = u * 2.0f - 1.0f;
+                }
+                float sh = 0.28209479177387814f;
+                sh = (g == 1) ? (-0.48860251190291987f * v[1]) : sh;
+                sh = (g == 2) ? (0.48860251190291987f * v[2]) : sh;
+                sh = (g == 3) ? (-0.48860251190291987f * v[0]) : sh;
+                B[j][0] = sh;
+                B[j][4] = geo_tail;
+            }
+            mlp_layer<5, 4>(lds + BL::H0, lane, B, D);
+            to_operand<4, true>(D, B);
+            mlp_layer<16, 4>(lds + BL::H1, lane, B, D);
+            to_operand<4, true>(D, B);
+            mlp_layer<16, 1>(lds + BL::H2, lane, B, D);
+#pragma unroll
+            for (int j = 0; j < NT; ++j) {
+                const int64_t s = tile * 64 + 16 * j + c;
+                float o3[3];
+#pragma unroll
+                for (int a = 0; a < 3; ++a) o3[a] = 1.0f / (1.0f + det_expf(-D[j][0][a]));
+                if (store_lane && s < A.n) {
+                    A.rgb[3 * s] = o3[0];
+                    A.rgb[3 * s + 1] = o3[1];
+                    A.rgb[3 * s + 2] = o3[2];
+                }
+            }
+        }
+    }
+}
+
+// ---- standalone hash-grid encode (one lane per point, all levels) ------------------------------
+struct HashArgs {
+    int64_t n;
+    const float *x, *t;
+    float *out;
+    int n_levels, table_dtype, temporal;
+    const void *table;
+    float scale[CED_MAX_LEVELS];
+    uint32_t res[CED_MAX_LEVELS], offset[CED_MAX_LEVELS], size[CED_MAX_LEVELS], hashed[CED_MAX_LEVELS];
+};
+
+__global__ __launch_bounds__(256) void hash_encode_kernel(HashArgs A)
+{
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= A.n) return;
+    float x[3];
+#pragma unroll
+    for (int a = 0; a < 3; ++a) x[a] = __builtin_fminf(__builtin_fmaxf(A.x[3 * i + a], 0.0f), 1.0f);
+    int k_lo = 0;
+    float t_frac = 0.0f;
+    if (A.temporal) temporal_keyframe(A.t ? A.t[i] : 0.0f, k_lo, t_frac);
+    float *o = A.out + i * 2 * A.n_levels;
+#pragma unroll
+    for (int l = 0; l < CED_MAX_LEVELS; ++l) {
+        if (l < A.n_levels) {
+            LevelConst L;
+            const bool hs = A.hashed[l] != 0;
+            L.scale = A.scale[l];
+            L.sy = hs ? 2654435761u : A.res[l];
+            L.sz = hs ? 805459861u : A.res[l] * A.res[l];
+            L.offset = A.offset[l];
+            L.size = A.size[l];
+            L.hashed = A.hashed[l];
+            float f0, f1;
+            hash_level(L, A.table, A.table_dtype, A.temporal, x, k_lo, t_frac, f0, f1);
+            o[2 * l] = f0;
+            o[2 * l + 1] = f1;
+        }
+    }
+}
+
+static int validate_hash(const ced_hash_desc *h, const char *who)
+{
+    CED_REQUIRE(h != nullptr, "%s: null hash descriptor", who);
+    CED_REQUIRE(h->n_levels >= 1 && h->n_levels <= CED_MAX_LEVELS, "%s: n_levels=%d out of range", who, h->n_levels);
+    CED_REQUIRE(h->table_dtype == 0 || h->table_dtype == 1, "%s: table_dtype must be 0 (f32) or 1 (f16)", who);
+    CED_REQUIRE(h->table != nullptr, "%s: null hash table", who);
+    for (int l = 0; l < h->n_levels; ++l) {
+        CED_REQUIRE(h->size[l] > 0, "%s: level %d has zero entries", who, l);
+        if (h->hashed[l])
+            CED_REQUIRE((h->size[l] & (h->size[l] - 1)) == 0, "%s: hashed level %d size %u is not a power of two", who, l,
+                        h->size[l]);
+        else
+            CED_REQUIRE((uint64_t)h->res[l] * h->res[l] * h->res[l] <= h->size[l],
+                        "%s: dense level %d smaller than res^3", who, l);
+        CED_REQUIRE((uint64_t)h->offset[l] + h->size[l] <= h->total_entries, "%s: level %d exceeds the table", who, l);
+    }
+    return CED_OK;
+}
+
+static int launch_field(const ced_field_desc *d, FieldArgs &A, void *stream)
+{
+    int rc = validate_hash(&d->hash, "field_forward");
+    if (rc) return rc;
+    if (d->hash.n_levels != 16) {
+        set_error("field_forward: the fused kernel needs n_levels == 16 (got %d)", d->hash.n_levels);
+        return CED_E_UNSUPPORTED;
+    }
+    CED_REQUIRE(d->time_mode >= 0 && d->time_mode <= 2, "field_forward: time_mode=%d", d->time_mode);
+    CED_REQUIRE(d->packed_weights != nullptr, "field_forward: null packed_weights");
+    CED_REQUIRE((int64_t)d->packed_floats == ced_packed_weight_floats(d->use_div_offsets, d->time_mode),
+                "field_forward: packed_floats=%llu does not match this configuration",
+                (unsigned long long)d->packed_floats);
+    for (int i = 0; i < 6; ++i) A.aabb[i] = d->aabb[i];
+    A.moving_step = d->moving_step;
+    A.use_div = d->use_div_offsets ? 1 : 0;
+    A.time_mode = d->time_mode;
+    A.weights = d->packed_weights;
+    A.table_dtype = d->hash.table_dtype;
+    A.temporal = d->hash.temporal ? 1 : 0;
+    A.table = d->hash.table;
+    for (int l = 0; l < CED_MAX_LEVELS; ++l) {
+        A.scale[l] = d->hash.scale[l];
+        A.res[l] = d->hash.res[l];
+        A.offset[l] = d->hash.offset[l];
+        A.size[l] = d->hash.size[l];
+        A.hashed[l] = d->hash.hashed[l];
+    }
+    const int64_t n_tiles = (A.n + 63) / 64;
+    int64_t blocks = (n_tiles + FIELD_WAVES - 1) / FIELD_WAVES;
+    if (blocks > 256) blocks = 256;     // one resident workgroup per CU, persistent over tiles
+    if (d->time_mode)
+        hipLaunchKernelGGL(field_kernel<true>, dim3((unsigned)blocks), dim3(FIELD_THREADS), 0, (hipStream_t)stream, A);
+    else
+        hipLaunchKernelGGL(field_kernel<false>, dim3((unsigned)blocks), dim3(FIELD_THREADS), 0, (hipStream_t)stream, A);
+    return check_launch("field_forward");
+}
+
+}  // namespace ced
+
+extern "C" int64_t ced_packed_weight_floats(int use_div_offsets, int time_mode)
+{
+    (void)use_div_offsets;
+    return time_mode ? ced::Blob<true>::TOTAL : ced::Blob<false>::TOTAL;
+}
+
+// Host-side reorder into MFMA A-fragment order: element (row p, input k) of a layer goes to
+// [nb = p/16][q = (k/4)/4][lane = (k%4)*16 + p%16][s = (k/4)%4].
+extern "C" int ced_pack_field_weights(int use_div_offsets, int time_mode, const float *m_w0, const float *m_w1,
+                                      const float *m_w2, const float *m_w3, const float *b_w0, const float *b_w1,
+                                      const float *h_w0, const float *h_w1, const float *h_w2, float *out)
+{
+    CED_REQUIRE(m_w0 && m_w1 && m_w2 && m_w3 && b_w0 && b_w1 && h_w0 && h_w1 && h_w2 && out,
+                "pack_field_weights: null pointer");
+    CED_REQUIRE(time_mode >= 0 && time_mode <= 2, "pack_field_weights: time_mode=%d", time_mode);
+    const bool te = time_mode != 0;
+    const int64_t total = ced_packed_weight_floats(use_div_offsets, time_mode);
+    for (int64_t i = 0; i < total; ++i) out[i] = 0.0f;
+    struct L { const float *w; int n_out, n_in, nb, ks, off; int row_rot; };
+    const int base_in = te ? 41 : 32;
+    const int n_mo = use_div_offsets ? 6 : 3;
+    const int ksb0 = te ? 11 : 8;
+    int offs[9];
+    if (te) {
+        using B = ced::Blob<true>;
+        int o[9] = { B::M0, B::M1, B::M2, B::M3, B::B0, B::B1, B::H0, B::H1, B::H2 };
+        for (int i = 0; i < 9; ++i) offs[i] = o[i];
+    } else {
+        using B = ced::Blob<false>;
+        int o[9] = { B::M0, B::M1, B::M2, B::M3, B::B0, B::B1, B::H0, B::H1, B::H2 };
+        for (int i = 0; i < 9; ++i) offs[i] = o[i];
+    }
+    const L layers[9] = {
+        { m_w0, 64, 32, 4, 8, offs[0], 0 },      { m_w1, 64, 64, 4, 16, offs[1], 0 },
+        { m_w2, 64, 64, 4, 16, offs[2], 0 },     { m_w3, n_mo, 64, 1, 16, offs[3], 0 },
+        { b_w0, 64, base_in, 4, ksb0, offs[4], 0 }, { b_w1, 16, 64, 1, 16, offs[5], 13 },
+        { h_w0, 64, 19, 4, 5, offs[6], 0 },      { h_w1, 64, 64, 4, 16, offs[7], 0 },
+        { h_w2, 3, 64, 1, 16, offs[8], 0 },
+    };
+    for (const L &l : layers) {
+        const int ks4 = ced::ks4_of(l.ks);
+        for (int p = 0; p < l.nb * 16; ++p) {
+            // accumulator row p holds output neuron (p + rot) mod 16 for the rotated layer
+            const int neuron = l.row_rot ? ((p + l.row_rot) & 15) : p;
+            if (neuron >= l.n_out) continue;
+            for (int k = 0; k < l.ks * 4; ++k) {
+                if (k >= l.n_in) continue;
+                const int S = k / 4, kk = k % 4;
+                const int lane = kk * 16 + (p % 16);
+                const int64_t idx = l.off + (((int64_t)(p / 16) * ks4 + S / 4) * 64 + lane) * 4 + (S % 4);
+                out[idx] = l.w[(int64_t)neuron * l.n_in + k];
+            }
+        }
+    }
+    return CED_OK;
+}
+
+extern "C" int ced_field_forward(const ced_field_desc *desc, int64_t n, const float *positions, const float *t,
+                                 const float *directions, float *rgb, float *sigma, float *geo, void *stream)
+{
+    CED_REQUIRE(desc != nullptr, "field_forward: null descriptor");
+    CED_REQUIRE(n >= 0, "field_forward: n < 0");
+    if (n == 0) return CED_OK;
+    CED_REQUIRE(positions && t && sigma, "field_forward: null positions/t/sigma");
+    CED_REQUIRE((directions != nullptr) == (rgb != nullptr), "field_forward: directions and rgb go together");
+    ced::FieldArgs A{};
+    A.n = n;
+    A.pos = positions; A.t = t; A.dir = directions;
+    A.rays_mode = 0; A.t_per_ray = 0; A.want_rgb = rgb ? 1 : 0;
+    A.rgb = rgb; A.sigma = sigma; A.geo = geo;
+    return ced::launch_field(desc, A, stream);
+}
+
+extern "C" int ced_field_forward_rays(const ced_field_desc *desc, int64_t n, const float *rays_o, const float *rays_d,
+                                      const int64_t *ray_indices, const float *t_starts, const float *t_ends,
+                                      const float *timestamps, int32_t t_per_ray, int32_t want_rgb, float *rgb,
+                                      float *sigma, void *stream)
+{
+    CED_REQUIRE(desc != nullptr, "field_forward_rays: null descriptor");
+    CED_REQUIRE(n >= 0, "field_forward_rays: n < 0");
+    if (n == 0) return CED_OK;
+    CED_REQUIRE(rays_o && rays_d && ray_indices && t_starts && t_ends && timestamps && sigma,
+                "field_forward_rays: null pointer");
+    CED_REQUIRE(!want_rgb || rgb, "field_forward_rays: want_rgb without an rgb buffer");
+    ced::FieldArgs A{};
+    A.n = n;
+    A.rays_o = rays_o; A.rays_d = rays_d; A.ray_idx = ray_indices;
+    A.t0 = t_starts; A.t1 = t_ends; A.timestamps = timestamps;
+    A.rays_mode = 1; A.t_per_ray = t_per_ray ? 1 : 0; A.want_rgb = want_rgb ? 1 : 0;
+    A.rgb = rgb; A.sigma = sigma; A.geo = nullptr;
+    return ced::launch_field(desc, A, stream);
+}
+
+extern "C" int ced_hash_encode(const ced_hash_desc *desc, int64_t n, const float *x, const float *t, float *out,
+                               void *stream)
+{
+    int rc = ced::validate_hash(desc, "hash_encode");
+    if (rc) return rc;
+    CED_REQUIRE(n >= 0, "hash_encode: n < 0");
+    if (n == 0) return CED_OK;
+    CED_REQUIRE(x && out, "hash_encode: null pointer");
+    ced::HashArgs A{};
+    A.n = n; A.x = x; A.t = t; A.out = out;
+    A.n_levels = desc->n_levels; A.table_dtype = desc->table_dtype; A.temporal = desc->temporal ? 1 : 0;
+    A.table = desc->table;
+    for (int l = 0; l < CED_MAX_LEVELS; ++l) {
+        A.scale[l] = desc->scale[l]; A.res[l] = desc->res[l]; A.offset[l] = desc->offset[l];
+        A.size[l] = desc->size[l]; A.hashed[l] = desc->hashed[l];
+    }
+    hipLaunchKernelGGL(ced::hash_encode_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, A);
+    return ced::check_launch("hash_encode");
+}

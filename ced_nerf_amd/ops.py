@@ -1,0 +1,234 @@
+"""Torch-tensor front-end of the C ABI (``include/cednerf_hip.h``).
+
+PyTorch is used for device memory and streams only; all arithmetic happens in the HIP kernels.
+Every wrapper validates device / dtype / contiguity (mirroring the reference's asserts,
+cednerf/render.py:16-22,74-79) and enqueues on the current torch stream.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from typing import Dict, Optional, Tuple
+
+import numpy as np
+import torch
+
+from . import _lib
+from .hashgrid import level_tables
+
+
+def _stream() -> C.c_void_p:
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _chk(t: Optional[torch.Tensor], dtype: torch.dtype, name: str, allow_none: bool = False):
+    if t is None:
+        if allow_none:
+            return None
+        raise ValueError(f"{name} is required")
+    if not t.is_cuda:
+        raise NotImplementedError(f"Only support cuda inputs ({name} is on {t.device}).")
+    if t.dtype != dtype:
+        raise TypeError(f"{name} must be {dtype}, got {t.dtype}")
+    if not t.is_contiguous():
+        raise ValueError(f"{name} must be contiguous")
+    return t
+
+
+def _p(t: Optional[torch.Tensor]) -> C.c_void_p:
+    return C.c_void_p(0 if t is None else t.data_ptr())
+
+
+def _as_u8(t: Optional[torch.Tensor]) -> Optional[torch.Tensor]:
+    if t is None:
+        return None
+    return t.view(torch.uint8) if t.dtype == torch.bool else t
+
+
+# ----------------------------------------------------------------------------------------------
+# field parameters on the device
+# ----------------------------------------------------------------------------------------------
+def make_hash_desc(table: torch.Tensor, base_res: int, max_res: int, n_levels: int, log2_hashmap_size: int,
+                   temporal: bool = False) -> Tuple[_lib.HashDesc, Dict]:
+    tabs = level_tables(base_res, max_res, n_levels, log2_hashmap_size)
+    width = 8 if temporal else 2
+    if table.dtype not in (torch.float32, torch.float16):
+        raise TypeError("hash table must be float32 or float16")
+    if tuple(table.shape) != (tabs["total"], width) or not table.is_contiguous() or not table.is_cuda:
+        raise ValueError(f"hash table must be a contiguous cuda tensor of shape {(tabs['total'], width)}, "
+                         f"got {tuple(table.shape)} on {table.device}")
+    d = _lib.HashDesc()
+    d.n_levels = n_levels
+    d.table_dtype = 0 if table.dtype == torch.float32 else 1
+    d.temporal = int(bool(temporal))
+    for l in range(n_levels):
+        d.scale[l] = float(tabs["scale"][l])
+        d.res[l] = int(tabs["res"][l])
+        d.offset[l] = int(tabs["offset"][l])
+        d.size[l] = int(tabs["size"][l])
+        d.hashed[l] = int(tabs["hashed"][l])
+    d.table = table.data_ptr()
+    d.total_entries = int(tabs["total"])
+    return d, tabs
+
+
+def pack_field_weights(use_div_offsets: bool, time_mode: int, xyz_wrap, mlp_base, mlp_head) -> np.ndarray:
+    """Host: natural W[out][in] float32 arrays -> MFMA-fragment-order blob (ced_pack_field_weights)."""
+    L = _lib.lib()
+    mats = [np.ascontiguousarray(np.asarray(w, np.float32)) for w in list(xyz_wrap) + list(mlp_base) + list(mlp_head)]
+    base_in = 41 if time_mode else 32
+    n_mo = 6 if use_div_offsets else 3
+    want = [(64, 32), (64, 64), (64, 64), (n_mo, 64), (64, base_in), (16, 64), (64, 19), (64, 64), (3, 64)]
+    got = [m.shape for m in mats]
+    if got != want:
+        raise ValueError(f"weight shapes {got} do not match the DNGPradianceField layout {want}")
+    n = int(L.ced_packed_weight_floats(int(use_div_offsets), int(time_mode)))
+    out = np.zeros((n,), np.float32)
+    rc = L.ced_pack_field_weights(int(use_div_offsets), int(time_mode),
+                                  *[m.ctypes.data_as(C.c_void_p) for m in mats], out.ctypes.data_as(C.c_void_p))
+    _lib.check(rc, "pack_field_weights")
+    return out
+
+
+# ----------------------------------------------------------------------------------------------
+# marching
+# ----------------------------------------------------------------------------------------------
+def ray_aabb_intersect(rays_o, rays_d, aabbs, near_plane=-float("inf"), far_plane=float("inf"),
+                       miss_value=float("inf")):
+    _chk(rays_o, torch.float32, "rays_o"); _chk(rays_d, torch.float32, "rays_d"); _chk(aabbs, torch.float32, "aabbs")
+    assert rays_o.ndim == 2 and rays_o.shape[-1] == 3 and rays_o.shape == rays_d.shape
+    assert aabbs.ndim == 2 and aabbs.shape[-1] == 6
+    n, m = rays_o.shape[0], aabbs.shape[0]
+    t_mins = torch.empty((n, m), device=rays_o.device, dtype=torch.float32)
+    t_maxs = torch.empty_like(t_mins)
+    hits = torch.empty((n, m), device=rays_o.device, dtype=torch.bool)
+    rc = _lib.lib().ced_ray_aabb_intersect(n, _p(rays_o), _p(rays_d), m, _p(aabbs), near_plane, far_plane,
+                                           miss_value, _p(t_mins), _p(t_maxs), _p(hits), _stream())
+    _lib.check(rc, "ray_aabb_intersect")
+    return t_mins, t_maxs, hits
+
+
+def traverse_grids_raw(rays_o, rays_d, binaries, aabbs, near_planes, far_planes, step_size, cone_angle, limit,
+                       rays_mask, t_sorted, t_indices, hits, mode, base=None, counts=None, t_starts=None,
+                       t_ends=None, ray_indices=None, termination_planes=None):
+    L = _lib.lib()
+    n = rays_o.shape[0]
+    m, res = binaries.shape[0], binaries.shape[1]
+    rc = L.ced_traverse_grids(n, _p(rays_o), _p(rays_d), _p(_as_u8(binaries)), m, res, _p(aabbs), _p(near_planes),
+                              _p(far_planes), float(step_size), float(cone_angle), int(limit), _p(_as_u8(rays_mask)),
+                              _p(t_sorted), _p(t_indices), _p(_as_u8(hits)), int(mode), _p(base), _p(counts),
+                              _p(t_starts), _p(t_ends), _p(ray_indices), _p(termination_planes), _stream())
+    _lib.check(rc, "traverse_grids")
+
+
+# ----------------------------------------------------------------------------------------------
+# hash grid / field
+# ----------------------------------------------------------------------------------------------
+def hash_encode(desc: _lib.HashDesc, x: torch.Tensor, t: Optional[torch.Tensor] = None) -> torch.Tensor:
+    _chk(x, torch.float32, "x")
+    assert x.ndim == 2 and x.shape[-1] == 3
+    if t is not None:
+        _chk(t, torch.float32, "t")
+        assert t.numel() == x.shape[0]
+    out = torch.empty((x.shape[0], 2 * desc.n_levels), device=x.device, dtype=torch.float32)
+    rc = _lib.lib().ced_hash_encode(C.byref(desc), x.shape[0], _p(x), _p(t), _p(out), _stream())
+    _lib.check(rc, "hash_encode")
+    return out
+
+
+def field_forward(desc: _lib.FieldDesc, positions, t, directions=None, want_geo=False):
+    _chk(positions, torch.float32, "positions"); _chk(t, torch.float32, "t")
+    n = positions.shape[0]
+    assert positions.shape == (n, 3) and t.numel() == n
+    dev = positions.device
+    rgb = None
+    if directions is not None:
+        _chk(directions, torch.float32, "directions")
+        assert directions.shape == positions.shape, f"{positions.shape} v.s. {directions.shape}"
+        rgb = torch.empty((n, 3), device=dev, dtype=torch.float32)
+    sigma = torch.empty((n,), device=dev, dtype=torch.float32)
+    geo = torch.empty((n, 15), device=dev, dtype=torch.float32) if want_geo else None
+    rc = _lib.lib().ced_field_forward(C.byref(desc), n, _p(positions), _p(t), _p(directions), _p(rgb), _p(sigma),
+                                      _p(geo), _stream())
+    _lib.check(rc, "field_forward")
+    return rgb, sigma, geo
+
+
+def field_forward_rays(desc: _lib.FieldDesc, rays_o, rays_d, ray_indices, t_starts, t_ends, timestamps,
+                       t_per_ray: bool, want_rgb: bool):
+    _chk(rays_o, torch.float32, "rays_o"); _chk(rays_d, torch.float32, "rays_d")
+    _chk(ray_indices, torch.int64, "ray_indices")
+    _chk(t_starts, torch.float32, "t_starts"); _chk(t_ends, torch.float32, "t_ends")
+    _chk(timestamps, torch.float32, "timestamps")
+    n = ray_indices.shape[0]
+    assert t_starts.shape == (n,) and t_ends.shape == (n,)
+    if t_per_ray:
+        assert timestamps.numel() == rays_o.shape[0], "per-ray timestamps must have one entry per ray"
+    dev = rays_o.device
+    rgb = torch.empty((n, 3), device=dev, dtype=torch.float32) if want_rgb else None
+    sigma = torch.empty((n,), device=dev, dtype=torch.float32)
+    rc = _lib.lib().ced_field_forward_rays(C.byref(desc), n, _p(rays_o), _p(rays_d), _p(ray_indices), _p(t_starts),
+                                           _p(t_ends), _p(timestamps), int(bool(t_per_ray)), int(bool(want_rgb)),
+                                           _p(rgb), _p(sigma), _stream())
+    _lib.check(rc, "field_forward_rays")
+    return rgb, sigma
+
+
+# ----------------------------------------------------------------------------------------------
+# compositing
+# ----------------------------------------------------------------------------------------------
+def render_weights(packed_info, t_starts, t_ends, sigmas, prefix_trans=None, want=(True, True, True)):
+    _chk(packed_info, torch.int64, "packed_info"); _chk(t_starts, torch.float32, "t_starts")
+    _chk(t_ends, torch.float32, "t_ends"); _chk(sigmas, torch.float32, "sigmas")
+    _chk(prefix_trans, torch.float32, "prefix_trans", allow_none=True)
+    outs = [torch.empty_like(t_starts) if w else None for w in want]
+    rc = _lib.lib().ced_render_weights(packed_info.shape[0], _p(packed_info), _p(t_starts), _p(t_ends), _p(sigmas),
+                                       _p(prefix_trans), _p(outs[0]), _p(outs[1]), _p(outs[2]), _stream())
+    _lib.check(rc, "render_weights")
+    return tuple(outs)
+
+
+def accumulate_along_rays_(packed_info, weights, values, outputs):
+    _chk(packed_info, torch.int64, "packed_info"); _chk(weights, torch.float32, "weights")
+    _chk(values, torch.float32, "values", allow_none=True); _chk(outputs, torch.float32, "outputs")
+    n_rays = packed_info.shape[0]
+    C_ = outputs.shape[-1]
+    assert outputs.shape == (n_rays, C_)
+    if values is not None:
+        assert values.shape == (weights.shape[0], C_), f"Invalid shapes: {values.shape} vs {weights.shape}"
+    rc = _lib.lib().ced_accumulate_along_rays(n_rays, _p(packed_info), _p(weights), _p(values), C_, _p(outputs),
+                                              _stream())
+    _lib.check(rc, "accumulate_along_rays")
+    return outputs
+
+
+def visibility_mask(packed_info, t_starts, t_ends, sigmas, early_stop_eps, alpha_thre):
+    _chk(packed_info, torch.int64, "packed_info")
+    mask = torch.empty(t_starts.shape, device=t_starts.device, dtype=torch.bool)
+    rc = _lib.lib().ced_visibility_mask(packed_info.shape[0], _p(packed_info), _p(t_starts), _p(t_ends), _p(sigmas),
+                                        float(early_stop_eps), float(alpha_thre), _p(mask), _stream())
+    _lib.check(rc, "visibility_mask")
+    return mask
+
+
+def composite_prefix_(packed_info, t_starts, t_ends, sigmas, rgbs, rgb, opacity, depth):
+    _chk(packed_info, torch.int64, "packed_info"); _chk(rgbs, torch.float32, "rgbs")
+    for nm, t in (("rgb", rgb), ("opacity", opacity), ("depth", depth)):
+        _chk(t, torch.float32, nm)
+    rc = _lib.lib().ced_composite_prefix(packed_info.shape[0], _p(packed_info), _p(t_starts), _p(t_ends), _p(sigmas),
+                                         _p(rgbs), _p(rgb), _p(opacity), _p(depth), _stream())
+    _lib.check(rc, "composite_prefix")
+
+
+def composite_test_(sigmas, rgbs, t_start, t_end, pack_info, alive_indices, T_threshold, alpha_threshold, opacity,
+                    depth, rgb):
+    _chk(pack_info, torch.int64, "pack_info"); _chk(alive_indices, torch.int64, "alive_indices")
+    rc = _lib.lib().ced_composite_test(alive_indices.shape[0], _p(sigmas), _p(rgbs), _p(t_start), _p(t_end),
+                                       _p(pack_info), _p(alive_indices), float(T_threshold), float(alpha_threshold),
+                                       _p(opacity), _p(depth), _p(rgb), _stream())
+    _lib.check(rc, "composite_test")
+
+
+def finalize_pixels_(bkgd, rgb, opacity, depth):
+    _chk(bkgd, torch.float32, "render_bkgd", allow_none=True)
+    rc = _lib.lib().ced_finalize_pixels(rgb.shape[0], _p(bkgd), _p(rgb), _p(opacity), _p(depth), _stream())
+    _lib.check(rc, "finalize_pixels")

@@ -1,0 +1,67 @@
+"""Volume rendering of ray-packed samples: host mirror of cednerf/render.py over the HIP kernels."""
+from __future__ import annotations
+
+from typing import Callable, Optional, Tuple
+
+import torch
+from torch import Tensor
+
+from . import ops
+from .nerfacc_api import (_packed_info_from, accumulate_along_rays, render_transmittance_from_density,
+                          render_weight_from_density)
+
+
+def reduce_along_rays(ray_indices: Tensor, values: Tensor, n_rays: Optional[int] = None,
+                      weights: Optional[Tensor] = None, reduce: str = "mean") -> Tensor:
+    """cednerf/render.py:8-39 (training extras; plain torch in the reference as well)."""
+    assert ray_indices.dim() == 1 and values.dim() == 2
+    if not values.is_cuda:
+        raise NotImplementedError("Only support cuda inputs.")
+    if weights is not None:
+        assert values.dim() == 2 and values.shape[0] == weights.shape[0], \
+            "Invalid shapes: {} vs {}".format(values.shape, weights.shape)
+        src = weights * values
+    else:
+        src = values
+    if ray_indices.numel() == 0:
+        assert n_rays is not None
+        return torch.zeros((n_rays, src.shape[-1]), device=values.device)
+    if n_rays is None:
+        n_rays = int(ray_indices.max()) + 1
+    index = ray_indices.long()[:, None].expand(-1, src.shape[-1])
+    outputs = torch.zeros((n_rays, src.shape[-1]), device=values.device, dtype=src.dtype)
+    outputs.scatter_reduce_(0, index, src, reduce=reduce)
+    return outputs
+
+
+def render_weight_from_density_prefix(t_starts: Tensor, t_ends: Tensor, sigmas: Tensor, prefix_trans: Tensor,
+                                      packed_info: Optional[Tensor] = None, ray_indices: Optional[Tensor] = None,
+                                      n_rays: Optional[int] = None) -> Tuple[Tensor, Tensor, Tensor]:
+    """cednerf/render.py:42-56: (weights, trans, alphas) with a caller-supplied prefix transmittance."""
+    trans, alphas = render_transmittance_from_density(t_starts, t_ends, sigmas, packed_info, ray_indices, n_rays,
+                                                      prefix_trans)
+    return trans * alphas, trans, alphas
+
+
+@torch.no_grad()
+def rendering(t_starts: Tensor, t_ends: Tensor, ray_indices: Tensor, n_rays: int, rgb_sigma_fn: Callable,
+              render_bkgd: Optional[Tensor] = None):
+    """cednerf/render.py:58-176 (eval path): field -> weights -> rgb/opacity/depth per ray.
+    Returns (colors [n,3], opacities [n,1], depths [n,1], extras)."""
+    rgbs, sigma_results = rgb_sigma_fn(t_starts, t_ends, ray_indices)
+    sigmas = sigma_results["density"].squeeze(-1) if isinstance(sigma_results, dict) else sigma_results
+    assert rgbs.shape[-1] == 3, "rgbs must have 3 channels, got {}".format(rgbs.shape)
+    assert sigmas.shape == t_starts.shape, "sigmas must have shape of (N, 1)! Got {}".format(sigmas.shape)
+    packed = _packed_info_from(ray_indices, n_rays)
+    weights, trans, alphas = render_weight_from_density(t_starts, t_ends, sigmas, packed_info=packed)
+    extras = {"weights": weights, "alphas": alphas, "trans": trans, "sigmas": sigmas, "rgbs": rgbs}
+    colors = accumulate_along_rays(weights, values=rgbs, packed_info=packed)
+    opacities = accumulate_along_rays(weights, values=None, packed_info=packed)
+    depths = accumulate_along_rays(weights, values=(t_starts + t_ends)[..., None] / 2.0, packed_info=packed)
+    bk = None
+    if render_bkgd is not None:
+        bk = render_bkgd.to(colors.device, torch.float32).reshape(-1).contiguous()
+    op_flat = opacities.reshape(-1)
+    dp_flat = depths.reshape(-1)
+    ops.finalize_pixels_(bk, colors, op_flat, dp_flat)
+    return colors, opacities, depths, extras

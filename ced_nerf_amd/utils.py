@@ -1,0 +1,163 @@
+"""Render drivers: host mirror of cednerf/utils.py (render_image :46-150, render_image_test :153-318).
+
+Same signatures and return tuples as the reference; the per-sample work (positions, field,
+weights, per-ray accumulation) runs in the HIP kernels through `ced_nerf_amd.ops`.
+"""
+from __future__ import annotations
+
+import collections
+import random
+from typing import Optional
+
+import numpy as np
+import torch
+
+from . import ops
+from .nerfacc_api import OccGridEstimator, march_packed, ray_aabb_intersect, sort_intersections
+from .render import rendering
+
+# datasets/utils.py:8,13-15
+Rays = collections.namedtuple("Rays", ("origins", "viewdirs"))
+
+
+def namedtuple_map(fn, tup):
+    """Apply `fn` to each element of `tup` and cast to `tup`'s namedtuple."""
+    return type(tup)(*(None if x is None else fn(x) for x in tup))
+
+
+def set_random_seed(seed):
+    random.seed(seed)
+    np.random.seed(seed)
+    torch.manual_seed(seed)
+
+
+def trunc_exp(x: torch.Tensor) -> torch.Tensor:
+    """Forward of cednerf/utils.py:27-43 (exp evaluated in float32)."""
+    return torch.exp(x.float())
+
+
+def _flatten_rays(rays: Rays):
+    rays_shape = rays.origins.shape
+    if len(rays_shape) == 3:
+        height, width, _ = rays_shape
+        num_rays = height * width
+        rays = namedtuple_map(lambda r: r.reshape([num_rays] + list(r.shape[2:])), rays)
+    else:
+        num_rays, _ = rays_shape
+    return rays, rays_shape, num_rays
+
+
+@torch.no_grad()
+def render_image(
+    radiance_field: torch.nn.Module,
+    estimator: OccGridEstimator,
+    rays: Rays,
+    near_plane: float = 0.0,
+    far_plane: float = 1e10,
+    render_step_size: float = 1e-3,
+    render_bkgd: Optional[torch.Tensor] = None,
+    cone_angle: float = 0.0,
+    alpha_thre: float = 0.0,
+    test_chunk_size: int = 8192,
+    timestamps: Optional[torch.Tensor] = None,
+):
+    """Render the pixels of an image (cednerf/utils.py:46-150).
+    Returns (colors, opacities, depths, n_rendering_samples, extras[list per chunk])."""
+    if timestamps is None:
+        raise NotImplementedError("DNGPradianceField needs timestamps (dnerf path of cednerf/utils.py:78-86)")
+    rays, rays_shape, num_rays = _flatten_rays(rays)
+    results, extra_info = [], []
+    chunk = torch.iinfo(torch.int32).max if radiance_field.training else test_chunk_size
+    for i in range(0, num_rays, chunk):
+        chunk_rays = namedtuple_map(lambda r: r[i:i + chunk].contiguous().float(), rays)
+        ts = timestamps[i:i + chunk] if radiance_field.training else timestamps
+
+        def sigma_fn(t_starts, t_ends, ray_indices):
+            return radiance_field.query_rays(chunk_rays.origins, chunk_rays.viewdirs, ray_indices, t_starts, t_ends,
+                                             ts, want_rgb=False)[1]
+
+        def rgb_sigma_fn(t_starts, t_ends, ray_indices):
+            return radiance_field.query_rays(chunk_rays.origins, chunk_rays.viewdirs, ray_indices, t_starts, t_ends,
+                                             ts, want_rgb=True)
+
+        ray_indices, t_starts, t_ends = estimator.sampling(
+            chunk_rays.origins, chunk_rays.viewdirs, sigma_fn=sigma_fn, near_plane=near_plane, far_plane=far_plane,
+            render_step_size=render_step_size, stratified=radiance_field.training, cone_angle=cone_angle,
+            alpha_thre=alpha_thre)
+        rgb, opacity, depth, extras = rendering(t_starts, t_ends, ray_indices, n_rays=chunk_rays.origins.shape[0],
+                                                rgb_sigma_fn=rgb_sigma_fn, render_bkgd=render_bkgd)
+        results.append([rgb, opacity, depth, len(t_starts)])
+        extras["ray_indices"] = ray_indices
+        extras["t_starts"] = t_starts
+        extras["t_ends"] = t_ends
+        extra_info.append(extras)
+    colors, opacities, depths, n_rendering_samples = [
+        torch.cat(r, dim=0) if isinstance(r[0], torch.Tensor) else r for r in zip(*results)
+    ]
+    return (colors.view((*rays_shape[:-1], -1)), opacities.view((*rays_shape[:-1], -1)),
+            depths.view((*rays_shape[:-1], -1)), sum(n_rendering_samples), extra_info)
+
+
+@torch.no_grad()
+def render_image_test(
+    max_samples: int,
+    radiance_field: torch.nn.Module,
+    estimator: OccGridEstimator,
+    rays: Rays,
+    near_plane: float = 0.0,
+    far_plane: float = 1e10,
+    render_step_size: float = 1e-3,
+    render_bkgd: Optional[torch.Tensor] = None,
+    cone_angle: float = 0.0,
+    alpha_thre: float = 0.0,
+    early_stop_eps: float = 1e-4,
+    timestamps: Optional[torch.Tensor] = None,
+):
+    """Iterative eval renderer with per-iteration early termination (cednerf/utils.py:153-318).
+    Returns (rgb, opacity, depth, total_samples).  `alpha_thre` is accepted and unused, as in the
+    reference."""
+    if timestamps is None:
+        raise NotImplementedError("DNGPradianceField needs timestamps (dnerf path of cednerf/utils.py:186-194)")
+    rays, rays_shape, N_rays = _flatten_rays(rays)
+    rays_o = rays.origins.contiguous().float()
+    rays_d = rays.viewdirs.contiguous().float()
+    device = rays_o.device
+    opacity = torch.zeros(N_rays, 1, device=device)
+    depth = torch.zeros(N_rays, 1, device=device)
+    rgb = torch.zeros(N_rays, 3, device=device)
+    ray_mask = torch.ones(N_rays, device=device).bool()
+    min_samples = 1 if cone_angle == 0 else 4
+    iter_samples = total_samples = 0
+    near_planes = torch.full_like(rays_o[..., 0], fill_value=near_plane)
+    far_planes = torch.full_like(rays_o[..., 0], fill_value=far_plane)
+    aabbs = estimator.aabbs.contiguous()
+    t_mins, t_maxs, hits = ray_aabb_intersect(rays_o, rays_d, aabbs)
+    t_sorted, t_indices = sort_intersections(t_mins, t_maxs)
+    opc_thres = 1 - early_stop_eps
+    op_flat, dp_flat = opacity.view(-1), depth.view(-1)
+
+    while iter_samples < max_samples:
+        N_alive = ray_mask.sum().item()
+        if N_alive == 0:
+            break
+        N_samples = max(min(N_rays // N_alive, 64), min_samples)
+        iter_samples += N_samples
+        t_starts, t_ends, ray_indices, packed_info, termination_planes = march_packed(
+            rays_o, rays_d, estimator.binaries, aabbs, near_planes, far_planes, render_step_size, cone_angle,
+            N_samples, ray_mask, t_sorted, t_indices, hits)
+        if ray_indices.shape[0] > 0:
+            rgbs, sigmas = radiance_field.query_rays(rays_o, rays_d, ray_indices, t_starts, t_ends, timestamps,
+                                                     want_rgb=True)
+            ops.composite_prefix_(packed_info, t_starts, t_ends, sigmas, rgbs, rgb, op_flat, dp_flat)
+        near_planes = termination_planes
+        ray_mask = torch.logical_and(op_flat <= opc_thres, packed_info[:, 1] == N_samples)
+        total_samples += ray_indices.shape[0]
+
+    bk = None if render_bkgd is None else render_bkgd.to(device, torch.float32).reshape(-1).contiguous()
+    ops.finalize_pixels_(bk, rgb, op_flat, dp_flat)
+    return (rgb.view((*rays_shape[:-1], -1)), opacity.view((*rays_shape[:-1], -1)),
+            depth.view((*rays_shape[:-1], -1)), total_samples)
+
+
+# nerfacc's example name for the same role (BASELINE.json north_star)
+render_image_with_occgrid = render_image

@@ -1,0 +1,174 @@
+/*
+ * cednerf_hip.h -- C ABI of libcednerf_hip.so, the MI355X (gfx950) rendering hot path behind
+ * Ced-NeRF's Python API.
+ *
+ * The reference has no FFI of its own for this path: its native entry points are the Python
+ * bindings of two un-vendored CUDA packages (nerfacc's `nerfacc.cuda._C` ops and tiny-cuda-nn's
+ * torch modules) plus Taichi kernels called with torch tensors.  Each function below names the
+ * reference interface it replaces (file:line relative to /root/reference).
+ *
+ * Conventions
+ *   - every pointer is a DEVICE pointer unless the parameter is documented "host";
+ *   - tensors are dense, row-major, float32 unless stated; index tensors are int64 as in nerfacc;
+ *     boolean tensors are one byte per element (torch.bool storage);
+ *   - the library never allocates or frees user-visible memory and never synchronises the device:
+ *     outputs and scratch are caller-allocated, work is enqueued on `stream` (a hipStream_t passed
+ *     as void*, NULL = default stream);
+ *   - return value 0 = success, negative = error (CED_E_*); ced_last_error_string() describes the
+ *     last failure of the calling thread.  Nothing throws or aborts.
+ *   - arithmetic contract: IEEE binary32, no FMA contraction except where the algorithm states
+ *     one; dot products are ascending-k fused-multiply-add chains (the fp32 MFMA's native
+ *     behaviour); per-ray sums run in sample order.  See DESIGN.md, "Arithmetic contract".
+ */
+#ifndef CEDNERF_HIP_H
+#define CEDNERF_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define CED_MAX_LEVELS 16
+
+#define CED_OK 0
+#define CED_E_INVALID (-1)      /* bad argument (null pointer, negative size, unsupported option) */
+#define CED_E_LAUNCH (-2)       /* HIP launch / runtime error */
+#define CED_E_UNSUPPORTED (-3)  /* configuration outside what the kernels implement */
+
+/* Multi-resolution hash grid description (host struct, copied at launch).
+ * Replaces the tcnn `HashGrid` encoding built at cednerf/model.py:242-252; arithmetic spec
+ * cednerf/taichi_kernel/hash_encoder_half.py:67-161 (and hash_encoder_inter.py:121-199 when
+ * `temporal` != 0).  Level tables are computed by the host in float64. */
+typedef struct ced_hash_desc {
+    int32_t n_levels;            /* 1..16; the fused field kernel requires 16 */
+    int32_t table_dtype;         /* 0 = float32 entries, 1 = float16 entries */
+    int32_t temporal;            /* 0: entry = 2 features; 1: entry = 4 key-frames x 2 features */
+    int32_t reserved;
+    float scale[CED_MAX_LEVELS];
+    uint32_t res[CED_MAX_LEVELS];
+    uint32_t offset[CED_MAX_LEVELS];   /* first entry of the level */
+    uint32_t size[CED_MAX_LEVELS];     /* entries in the level */
+    uint32_t hashed[CED_MAX_LEVELS];   /* 1: xor-prime hash, 0: dense x + y*res + z*res^2 */
+    const void *table;           /* device: [total_entries][2 or 8] */
+    uint64_t total_entries;
+} ced_hash_desc;
+
+/* DNGPradianceField description (host struct).  Replaces the module built at
+ * cednerf/model.py:100-344 (xyz_wrap :200-222, direction_encoding :225-239, hash_encoder :242-252,
+ * mlp_base :280-290, mlp_head :291-309). */
+typedef struct ced_field_desc {
+    float aabb[6];
+    float moving_step;           /* model.py:151, train_real.py:104,136,169 */
+    int32_t use_div_offsets;     /* model.py:356-358 */
+    int32_t time_mode;           /* 0 none, 1 SinusoidalEncoder, 2 SinusoidalEncoderWithExp (model.py:386-396) */
+    int32_t reserved;
+    const float *packed_weights; /* device: blob written by ced_pack_field_weights */
+    uint64_t packed_floats;
+    ced_hash_desc hash;
+} ced_field_desc;
+
+int ced_version(void);
+const char *ced_last_error_string(void);
+
+/* Number of floats in the packed (MFMA-fragment-order) weight blob. */
+int64_t ced_packed_weight_floats(int use_div_offsets, int time_mode);
+
+/* HOST function: reorders natural-layout weights W[out][in] (row-major, host pointers) into the
+ * fragment-order blob the fused kernel stages into LDS.  Layer dims: xyz_wrap 32-64-64-64-(3|6),
+ * mlp_base (32|41)-64-16, mlp_head 19-64-64-3 (model.py:200-222,280-309).  `out` is host memory
+ * of ced_packed_weight_floats() floats; upload it and put the device address in
+ * ced_field_desc.packed_weights.  Replaces tcnn's flat `params` tensor layout. */
+int ced_pack_field_weights(int use_div_offsets, int time_mode,
+                           const float *m_w0, const float *m_w1, const float *m_w2, const float *m_w3,
+                           const float *b_w0, const float *b_w1,
+                           const float *h_w0, const float *h_w1, const float *h_w2,
+                           float *out);
+
+/* nerfacc.ray_aabb_intersect(rays_o, rays_d, aabbs, near_plane, far_plane, miss_value)
+ * -- call site cednerf/utils.py:215.  Outputs [n_rays, n_aabbs]. */
+int ced_ray_aabb_intersect(int64_t n_rays, const float *rays_o, const float *rays_d,
+                           int32_t n_aabbs, const float *aabbs,
+                           float near_plane, float far_plane, float miss_value,
+                           float *t_mins, float *t_maxs, uint8_t *hits, void *stream);
+
+/* nerfacc.traverse_grids(...) -- call sites cednerf/utils.py:241-264 and, via
+ * OccGridEstimator.sampling, cednerf/utils.py:115-125.  The caller allocates, so the op is split:
+ *   mode 0  count: writes counts[n_rays] and termination_planes (t_starts/t_ends/ray_indices unused);
+ *   mode 1  fill : writes samples of ray r at base[r] + i (base = exclusive scan of counts);
+ *   mode 2  over-allocate (nerfacc `over_allocate=True`): ray r owns slots [r*limit, (r+1)*limit),
+ *           counts[r] tells how many are valid; `base` unused; requires limit > 0.
+ * rays_mask may be NULL (all rays).  ray_indices may be NULL.  binaries: [n_grids,res,res,res]
+ * bytes; t_sorted/t_indices: [n_rays, 2*n_grids]; hits: [n_rays, n_grids]. */
+int ced_traverse_grids(int64_t n_rays, const float *rays_o, const float *rays_d,
+                       const uint8_t *binaries, int32_t n_grids, int32_t res, const float *aabbs,
+                       const float *near_planes, const float *far_planes,
+                       float step_size, float cone_angle, int32_t limit, const uint8_t *rays_mask,
+                       const float *t_sorted, const int64_t *t_indices, const uint8_t *hits,
+                       int32_t mode, const int64_t *base,
+                       int64_t *counts, float *t_starts, float *t_ends, int64_t *ray_indices,
+                       float *termination_planes, void *stream);
+
+/* hash_encoder(x): the tcnn HashGrid forward at cednerf/model.py:384 (spec
+ * hash_encoder_half.py:112-161).  x [n,3] in [0,1] (clamped), t [n] or NULL (temporal only),
+ * out [n, 2*n_levels] level-major (hash_encoder_half.py:339-345,385). */
+int ced_hash_encode(const ced_hash_desc *desc, int64_t n, const float *x, const float *t,
+                    float *out, void *stream);
+
+/* DNGPradianceField.forward(positions, t, directions) -- cednerf/model.py:468-488 (query_move
+ * :354-365, query_density :367-445, _query_rgb :447-466), fused into one kernel.
+ * dir/rgb may both be NULL (density only = query_density, model.py:367); geo [n,15] may be NULL
+ * (= results['base_mlp_out']). */
+int ced_field_forward(const ced_field_desc *desc, int64_t n, const float *positions, const float *t,
+                      const float *directions, float *rgb, float *sigma, float *geo, void *stream);
+
+/* The sigma_fn / rgb_sigma_fn closures of the render drivers (cednerf/utils.py:74-104,181-195)
+ * fused with the field: positions = o[ray] + d[ray]*(t0+t1)/2, t = timestamps[t_per_ray ? ray : 0].
+ * want_rgb == 0 evaluates the density only (sigma_fn). */
+int ced_field_forward_rays(const ced_field_desc *desc, int64_t n, const float *rays_o, const float *rays_d,
+                           const int64_t *ray_indices, const float *t_starts, const float *t_ends,
+                           const float *timestamps, int32_t t_per_ray, int32_t want_rgb,
+                           float *rgb, float *sigma, void *stream);
+
+/* nerfacc.render_weight_from_density / render_transmittance_from_density with packed_info
+ * [n_rays,2] = (start,count) -- call sites cednerf/render.py:52-54,81-87, cednerf/utils.py:274-281.
+ * prefix_trans is per sample (NULL = 1); weights/trans/alphas may each be NULL. */
+int ced_render_weights(int64_t n_rays, const int64_t *packed_info, const float *t_starts,
+                       const float *t_ends, const float *sigmas, const float *prefix_trans,
+                       float *weights, float *trans, float *alphas, void *stream);
+
+/* nerfacc.accumulate_along_rays(_): out[ray, :] += sum_i w_i * values[i, :] (values NULL: C must
+ * be 1 and the weights are summed) -- cednerf/render.py:158-169, cednerf/utils.py:282-299. */
+int ced_accumulate_along_rays(int64_t n_rays, const int64_t *packed_info, const float *weights,
+                              const float *values, int32_t n_channels, float *out, void *stream);
+
+/* nerfacc.render_visibility_from_density inside OccGridEstimator.sampling (cednerf/utils.py:115-125):
+ * mask[i] = trans_i >= early_stop_eps && (alpha_thre <= 0 || alpha_i >= alpha_thre). */
+int ced_visibility_mask(int64_t n_rays, const int64_t *packed_info, const float *t_starts,
+                        const float *t_ends, const float *sigmas, float early_stop_eps, float alpha_thre,
+                        uint8_t *mask, void *stream);
+
+/* One pass of cednerf/utils.py:274-299 (render_weight_from_density with
+ * prefix_trans = 1 - opacity[ray], then the three accumulate_along_rays_) fused per ray, in place.
+ * packed_info [n_rays,2] indexes the sample arrays; rgbs [S,3]. */
+int ced_composite_prefix(int64_t n_rays, const int64_t *packed_info, const float *t_starts,
+                         const float *t_ends, const float *sigmas, const float *rgbs,
+                         float *rgb, float *opacity, float *depth, void *stream);
+
+/* composite_test -- cednerf/taichi_kernel/volume_render_test.py:4-59 (same arguments, same
+ * in-place semantics; alive_indices entries are set to -1 when a ray finishes). */
+int ced_composite_test(int64_t n_alive, const float *sigmas, const float *rgbs, const float *t_start,
+                       const float *t_end, const int64_t *pack_info, int64_t *alive_indices,
+                       float T_threshold, float alpha_threshold,
+                       float *opacity, float *depth, float *rgb, void *stream);
+
+/* Tail of render_image_test / rendering (cednerf/utils.py:310-311, cednerf/render.py:170-174):
+ * rgb += bkgd * (1 - opacity); depth /= max(opacity, FLT_EPSILON).  bkgd: device [3] or NULL. */
+int ced_finalize_pixels(int64_t n_rays, const float *bkgd, float *rgb, const float *opacity,
+                        float *depth, void *stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* CEDNERF_HIP_H */

@@ -1,0 +1,318 @@
+"""GPU parity tests: the HIP path (through the C ABI) against the CPU oracle on the same seeded inputs.
+
+Bars (BASELINE.json north_star): sample indices / counts bit-exact; composited RGB / depth within
+1e-4 abs.  Because the kernels and the oracle share one arithmetic contract, most float outputs
+are in fact compared bit for bit.
+"""
+import numpy as np
+import pytest
+import torch
+
+from conftest import assert_bitexact
+
+pytestmark = pytest.mark.gpu
+
+DEV = "cuda:0"
+
+
+def T(a, dtype=None):
+    t = torch.from_numpy(np.ascontiguousarray(a))
+    if dtype is not None:
+        t = t.to(dtype)
+    return t.to(DEV)
+
+
+def N(t):
+    return t.detach().cpu().numpy()
+
+
+def random_rays(n, seed, radius=4.0, spread=1.2):
+    rng = np.random.default_rng(seed)
+    o = rng.normal(size=(n, 3)); o = o / np.linalg.norm(o, axis=1, keepdims=True) * radius
+    target = rng.uniform(-spread, spread, size=(n, 3))
+    d = target - o; d = d / np.linalg.norm(d, axis=1, keepdims=True)
+    o = o.astype(np.float32); d = d.astype(np.float32)
+    # edge cases: axis-parallel rays, zero components, origins inside the box, rays that miss
+    o[0] = [-2, 0.01, 0.01]; d[0] = [1, 0, 0]
+    o[1] = [0.1, 0.2, -3]; d[1] = [0, 0, 1]
+    o[2] = [0, 0, 0]; d[2] = [0.6, 0.8, 0]
+    o[3] = [5, 5, 5]; d[3] = [1, 0, 0]
+    o[4] = [0.3, -0.2, 0.1]; d[4] = [-0.57735026, 0.57735026, 0.57735026]
+    return o, d
+
+
+@pytest.mark.parametrize("levels", [1, 2, 4])
+def test_ray_aabb_intersect(oracle, levels):
+    from ced_nerf_amd import nerfacc_api as A
+    o, d = random_rays(5000, 1)
+    aabbs = oracle.make_aabbs([-1, -1, -1, 1, 1, 1], levels)
+    want = oracle.ray_aabb_intersect(o, d, aabbs)
+    got = A.ray_aabb_intersect(T(o), T(d), T(aabbs))
+    for g, w, nm in zip(got, want, ("t_mins", "t_maxs", "hits")):
+        assert_bitexact(N(g), w, nm)
+
+
+def _scene(name, w, h, regime="trained", **kw):
+    from ced_nerf_amd import synthetic as S
+    return S.make_scene(name, w, h, regime, **kw)
+
+
+@pytest.mark.parametrize("name,limit,masked", [("dnerf", 0, False), ("dnerf", 7, True), ("hypernerf", 0, False),
+                                               ("hypernerf", 4, True), ("dynerf", 0, False), ("dynerf", 16, True)])
+def test_traverse_grids(oracle, name, limit, masked):
+    from ced_nerf_amd import nerfacc_api as A
+    sc = _scene(name, 96, 64, log2_hashmap_size=15)
+    o = sc["origins"].reshape(-1, 3); d = sc["viewdirs"].reshape(-1, 3)
+    n = o.shape[0]
+    cfg = sc["cfg"]
+    aabbs = oracle.make_aabbs(cfg["aabb"], cfg["grid_levels"])
+    near = np.full(n, cfg["near_plane"], np.float32); far = np.full(n, cfg["far_plane"], np.float32)
+    mask = None
+    if masked:
+        mask = np.random.default_rng(0).uniform(size=n) < 0.7
+    want = oracle.traverse_grids(o, d, sc["binaries"], aabbs, near, far, cfg["render_step_size"], cfg["cone_angle"],
+                                 limit, False, mask)
+    assert want["t_starts"].shape[0] > 1000
+    i_, s_, term = A.traverse_grids(T(o), T(d), T(sc["binaries"]), T(aabbs), T(near), T(far),
+                                    cfg["render_step_size"], cfg["cone_angle"], limit if limit else None, False,
+                                    None if mask is None else T(mask))
+    assert_bitexact(N(s_.packed_info), want["packed_info"], "packed_info")
+    assert_bitexact(N(s_.ray_indices), want["ray_indices"], "ray_indices")
+    assert_bitexact(N(i_.vals[i_.is_left]), want["t_starts"], "t_starts")
+    assert_bitexact(N(i_.vals[i_.is_right]), want["t_ends"], "t_ends")
+    assert_bitexact(N(term), want["termination_planes"], "termination_planes")
+    if limit:
+        # nerfacc's over-allocated layout: same samples after the caller-side compaction
+        i2, s2, term2 = A.traverse_grids(T(o), T(d), T(sc["binaries"]), T(aabbs), T(near), T(far),
+                                         cfg["render_step_size"], cfg["cone_angle"], limit, True,
+                                         None if mask is None else T(mask))
+        assert_bitexact(N(i2.vals[i2.is_left]), want["t_starts"], "t_starts (over-allocated)")
+        assert_bitexact(N(i2.vals[i2.is_right]), want["t_ends"], "t_ends (over-allocated)")
+        assert_bitexact(N(s2.ray_indices[s2.is_valid]), want["ray_indices"], "ray_indices (over-allocated)")
+        assert_bitexact(N(s2.packed_info[:, 1]), want["packed_info"][:, 1], "counts (over-allocated)")
+        assert_bitexact(N(s2.packed_info[:, 0]), np.arange(n) * limit, "starts (over-allocated)")
+        assert_bitexact(N(term2), want["termination_planes"], "termination_planes (over-allocated)")
+
+
+def test_traverse_known_answer(oracle):
+    """SURVEY Appendix B.2 on the GPU."""
+    from ced_nerf_amd import nerfacc_api as A
+    b = np.zeros((1, 2, 2, 2), bool); b[0, 1, 0, 0] = True
+    o = np.array([[-2, -.5, -.5]], np.float32); d = np.array([[1, 0, 0]], np.float32)
+    aabbs = np.array([[-1, -1, -1, 1, 1, 1]], np.float32)
+    i_, s_, term = A.traverse_grids(T(o), T(d), T(b), T(aabbs), T(np.zeros(1, np.float32)),
+                                    T(np.full(1, 1e10, np.float32)), 0.25, 0.0)
+    assert N(i_.vals[i_.is_left]).tolist() == [2.0, 2.25, 2.5, 2.75]
+    assert N(i_.vals[i_.is_right]).tolist() == [2.25, 2.5, 2.75, 3.0]
+    assert N(s_.packed_info).tolist() == [[0, 4]] and N(term).tolist() == [3.0]
+
+
+def _points(n, seed):
+    rng = np.random.default_rng(seed)
+    x = rng.uniform(0, 1, size=(n, 3)).astype(np.float32)
+    x[0] = [0, 0, 0]; x[1] = [1, 1, 1]; x[2] = [0.5, 0.5, 0.5]; x[3] = [1, 0, 1]; x[4] = [-0.2, 1.3, 0.5]
+    return x
+
+
+@pytest.mark.parametrize("max_res,log2T,dtype,temporal", [
+    (1024, 21, np.float32, False), (1024, 21, np.float16, False), (4096, 19, np.float32, False),
+    (8192, 15, np.float16, False), (1024, 17, np.float16, True), (4096, 17, np.float32, True)])
+def test_hash_encode(oracle, max_res, log2T, dtype, temporal):
+    from ced_nerf_amd import ops, synthetic as S
+    p = S.init_field_params([-1, -1, -1, 1, 1, 1], 1e-4, max_res, log2T, regime="trained", table_dtype=dtype,
+                            temporal_hash=temporal)
+    of = oracle.OracleField({"hash": p["hash"]})
+    x = _points(20000, 3)
+    t = np.random.default_rng(4).uniform(0, 1, size=x.shape[0]).astype(np.float32)
+    t[:3] = [0.0, 1.0, 1.0 / 3.0]
+    want = of.hash_encode(x, t if temporal else None)
+    desc, _ = ops.make_hash_desc(T(p["hash"]["table"]), 16, max_res, 16, log2T, temporal)
+    got = ops.hash_encode(desc, T(x), T(t) if temporal else None)
+    assert_bitexact(N(got), want, "hash features")
+    assert np.abs(want).max() > 0.1
+
+
+FIELD_CASES = [
+    dict(), dict(use_div_offsets=True), dict(use_time_embedding=True),
+    dict(use_time_embedding=True, use_time_attenuation=True, use_div_offsets=True),
+    dict(table_dtype=np.float16), dict(temporal_hash=True, table_dtype=np.float16, use_time_embedding=True),
+]
+
+
+@pytest.mark.parametrize("case", range(len(FIELD_CASES)))
+@pytest.mark.parametrize("regime", ["init", "trained"])
+def test_field_forward(oracle, case, regime):
+    from ced_nerf_amd import synthetic as S
+    from ced_nerf_amd.model import DNGPradianceField
+    kw = dict(FIELD_CASES[case])
+    aabb = [-1.5, -1.5, -1.5, 1.5, 1.5, 1.5]
+    p = S.init_field_params(aabb, 1.0 / 64 if regime == "trained" else 1e-4, 1024, 17, regime=regime, seed=7 + case,
+                            **kw)
+    of = oracle.OracleField(p)
+    rng = np.random.default_rng(11)
+    n = 5000 + 37          # ragged tail: not a multiple of the 64-sample wave tile
+    pos = rng.uniform(-1.6, 1.6, size=(n, 3)).astype(np.float32)      # some points outside the aabb
+    pos[0] = [1.5, 0, 0]; pos[1] = [-1.5, -1.5, -1.5]
+    t = rng.uniform(0, 1, size=(n, 1)).astype(np.float32); t[2] = 0; t[3] = 1
+    d = rng.normal(size=(n, 3)).astype(np.float32)
+    want = of.forward(pos, t, d, want_geo=True)
+    f = DNGPradianceField.from_params(p, DEV).eval()
+    rgb, res = f(T(pos), T(t), T(d))
+    assert rgb.shape == (n, 3) and res["density"].shape == (n, 1) and res["base_mlp_out"].shape == (n, 15)
+    assert_bitexact(N(res["base_mlp_out"]), want["base_mlp_out"], "base_mlp_out")
+    assert_bitexact(N(res["density"])[:, 0], want["density"], "density")
+    assert_bitexact(N(rgb), want["rgb"], "rgb")
+    assert (want["density"] == 0).any() and (want["density"] > 0).any()
+    dens = f.query_density(T(pos), T(t))
+    assert_bitexact(N(dens["density"])[:, 0], want["density"], "query_density")
+
+
+def test_field_small_and_empty(oracle):
+    from ced_nerf_amd import synthetic as S
+    from ced_nerf_amd.model import DNGPradianceField
+    p = S.init_field_params([-1, -1, -1, 1, 1, 1], 1e-3, 1024, 15, regime="trained")
+    of = oracle.OracleField(p)
+    f = DNGPradianceField.from_params(p, DEV).eval()
+    for n in (0, 1, 15, 16, 17, 63, 64, 65):
+        rng = np.random.default_rng(n)
+        pos = rng.uniform(-1, 1, size=(n, 3)).astype(np.float32)
+        t = rng.uniform(0, 1, size=(n, 1)).astype(np.float32)
+        d = rng.normal(size=(n, 3)).astype(np.float32)
+        rgb, res = f(T(pos), T(t), T(d))
+        assert rgb.shape == (n, 3)
+        if n:
+            want = of.forward(pos, t, d)
+            assert_bitexact(N(rgb), want["rgb"], f"rgb n={n}")
+            assert_bitexact(N(res["density"])[:, 0], want["density"], f"density n={n}")
+
+
+def _packed_problem(n_rays, seed, empty_frac=0.3):
+    rng = np.random.default_rng(seed)
+    counts = rng.integers(0, 40, size=n_rays)
+    counts[rng.uniform(size=n_rays) < empty_frac] = 0
+    base = np.cumsum(counts) - counts
+    S_ = int(counts.sum())
+    packed = np.stack([base, counts], -1).astype(np.int64)
+    t0 = np.sort(rng.uniform(0, 5, size=S_)).astype(np.float32)
+    t1 = (t0 + rng.uniform(1e-3, 2e-2, size=S_)).astype(np.float32)
+    sig = (rng.uniform(0, 1, size=S_) ** 4 * 300).astype(np.float32)
+    rgbs = rng.uniform(0, 1, size=(S_, 3)).astype(np.float32)
+    return packed, t0, t1, sig, rgbs
+
+
+def test_compositing_ops(oracle):
+    from ced_nerf_amd import nerfacc_api as A, ops, render as R
+    packed, t0, t1, sig, rgbs = _packed_problem(3000, 5)
+    n_rays = packed.shape[0]
+    prefix = np.random.default_rng(6).uniform(0, 1, size=t0.shape[0]).astype(np.float32)
+    for pf in (None, prefix):
+        w, tr, al = oracle.render_weight_from_density(t0, t1, sig, packed, pf)
+        gw, gtr, gal = A.render_weight_from_density(T(t0), T(t1), T(sig), packed_info=T(packed),
+                                                    prefix_trans=None if pf is None else T(pf))
+        assert_bitexact(N(gw), w, "weights"); assert_bitexact(N(gtr), tr, "trans"); assert_bitexact(N(gal), al, "alphas")
+    gw2, gtr2, gal2 = R.render_weight_from_density_prefix(T(t0), T(t1), T(sig), T(prefix), packed_info=T(packed))
+    assert_bitexact(N(gtr2), tr, "prefix trans"); assert_bitexact(N(gal2), al, "prefix alphas")
+    # ray_indices form
+    ri = np.repeat(np.arange(n_rays), packed[:, 1]).astype(np.int64)
+    gw3, _, _ = A.render_weight_from_density(T(t0), T(t1), T(sig), ray_indices=T(ri), n_rays=n_rays)
+    w0, _, _ = oracle.render_weight_from_density(t0, t1, sig, packed, None)
+    assert_bitexact(N(gw3), w0, "weights via ray_indices")
+    for vals, C_ in ((rgbs, 3), (None, 1)):
+        out = np.random.default_rng(8).uniform(size=(n_rays, C_)).astype(np.float32)
+        want = oracle.accumulate_along_rays_(w0, vals, packed, out.copy())
+        got = T(out.copy())
+        A.accumulate_along_rays_(T(w0), values=None if vals is None else T(vals), ray_indices=T(ri), outputs=got)
+        assert_bitexact(N(got), want, f"accumulate C={C_}")
+    got = A.accumulate_along_rays(T(w0), values=T(rgbs), ray_indices=T(ri), n_rays=n_rays)
+    want = oracle.accumulate_along_rays_(w0, rgbs, packed, np.zeros((n_rays, 3), np.float32))
+    assert_bitexact(N(got), want, "accumulate_along_rays")
+    for eps, thre in ((1e-4, 0.0), (1e-4, 1e-2), (0.0, 0.5)):
+        want = oracle.visibility_mask(t0, t1, sig, packed, eps, thre)
+        got = A.render_visibility_from_density(T(t0), T(t1), T(sig), packed_info=T(packed), early_stop_eps=eps,
+                                               alpha_thre=thre)
+        assert_bitexact(N(got), want, f"visibility eps={eps} thre={thre}")
+        assert 0 < want.mean() < 1
+
+
+def test_composite_test_kernel(oracle):
+    """cednerf/taichi_kernel/volume_render_test.py:composite_test on the GPU vs its C restatement."""
+    import ctypes as C
+    from ced_nerf_amd import ops
+    packed, t0, t1, sig, rgbs = _packed_problem(2000, 9)
+    n_alive = packed.shape[0]
+    rng = np.random.default_rng(10)
+    n_rays = 2500
+    alive = rng.permutation(n_rays)[:n_alive].astype(np.int64)
+    opacity = rng.uniform(0, 0.5, size=(n_rays, 1)).astype(np.float32)
+    depth = rng.uniform(0, 1, size=(n_rays, 1)).astype(np.float32)
+    rgb = rng.uniform(0, 1, size=(n_rays, 3)).astype(np.float32)
+    w_alive, w_op, w_dp, w_rgb = alive.copy(), opacity.copy(), depth.copy(), rgb.copy()
+    p = lambda a: a.ctypes.data_as(C.c_void_p)
+    oracle.lib().ced_o_composite_test(C.c_int64(n_alive), p(sig), p(rgbs), p(t0), p(t1), p(packed), p(w_alive),
+                                      C.c_float(1e-2), C.c_float(1e-3), p(w_op), p(w_dp), p(w_rgb))
+    g_alive, g_op, g_dp, g_rgb = T(alive), T(opacity), T(depth), T(rgb)
+    ops.composite_test_(T(sig)[:, None].contiguous(), T(rgbs), T(t0)[:, None].contiguous(),
+                        T(t1)[:, None].contiguous(), T(packed), g_alive, 1e-2, 1e-3, g_op, g_dp, g_rgb)
+    assert_bitexact(N(g_alive), w_alive, "alive_indices")
+    assert_bitexact(N(g_op), w_op, "opacity"); assert_bitexact(N(g_dp), w_dp, "depth"); assert_bitexact(N(g_rgb), w_rgb, "rgb")
+    assert (w_alive == -1).any() and (w_alive != -1).any()
+
+
+def _setup(oracle, sc):
+    from ced_nerf_amd.model import DNGPradianceField
+    from ced_nerf_amd.nerfacc_api import OccGridEstimator
+    from ced_nerf_amd.utils import Rays
+    cfg = sc["cfg"]
+    of = oracle.OracleField(sc["params"])
+    oest = oracle.OracleEstimator(cfg["aabb"], cfg["grid_resolution"], cfg["grid_levels"], sc["binaries"])
+    f = DNGPradianceField.from_params(sc["params"], DEV).eval()
+    est = OccGridEstimator(cfg["aabb"], cfg["grid_resolution"], cfg["grid_levels"]).to(DEV)
+    est.set_binaries(T(sc["binaries"]))
+    rays = Rays(origins=T(sc["origins"]), viewdirs=T(sc["viewdirs"]))
+    rk = dict(sc["render"]); rk["render_bkgd"] = T(rk["render_bkgd"])
+    return of, oest, f, est, rays, rk
+
+
+@pytest.mark.parametrize("name,regime,wh", [("dnerf", "trained", (80, 60)), ("dnerf", "init", (64, 48)),
+                                            ("hypernerf", "trained", (48, 64)), ("dynerf", "trained", (64, 48))])
+def test_render_image_test_parity(oracle, name, regime, wh):
+    """a1: render_image_test end to end; per-iteration sample counts bit-exact, pixels <= 1e-4."""
+    from ced_nerf_amd.utils import render_image_test
+    sc = _scene(name, wh[0], wh[1], regime, log2_hashmap_size=17)
+    of, oest, f, est, rays, rk = _setup(oracle, sc)
+    max_samples = 256 if regime == "init" else 1024
+    trace = []
+    w_rgb, w_op, w_dp, w_total = oracle.render_image_test(max_samples, of, oest, sc["origins"], sc["viewdirs"],
+                                                          timestamps=sc["timestamps"], trace=trace, **sc["render"])
+    rgb, op, dp, total = render_image_test(max_samples, f, est, rays, timestamps=T(sc["timestamps"]), **rk)
+    assert rgb.shape == (wh[1], wh[0], 3) and op.shape == (wh[1], wh[0], 1) and dp.shape == (wh[1], wh[0], 1)
+    assert total == w_total and total > 2000
+    assert np.abs(N(rgb) - w_rgb).max() <= 1e-4
+    assert np.abs(N(op) - w_op).max() <= 1e-4
+    assert np.abs(N(dp) - w_dp).max() <= 1e-4
+    assert_bitexact(N(rgb), w_rgb, "rgb (bit-exact)")
+    assert_bitexact(N(dp), w_dp, "depth (bit-exact)")
+
+
+@pytest.mark.parametrize("name,regime,wh", [("dnerf", "trained", (80, 60)), ("hypernerf", "trained", (48, 64)),
+                                            ("dynerf", "init", (40, 30))])
+def test_render_image_parity(oracle, name, regime, wh):
+    """a2/a3: render_image (sampling -> visibility filter -> rendering): surviving sample indices,
+    t_starts/t_ends and counts bit-exact per chunk; pixels <= 1e-4."""
+    from ced_nerf_amd.utils import render_image
+    sc = _scene(name, wh[0], wh[1], regime, log2_hashmap_size=17)
+    of, oest, f, est, rays, rk = _setup(oracle, sc)
+    chunk = 1000
+    w = oracle.render_image(of, oest, sc["origins"], sc["viewdirs"], timestamps=sc["timestamps"],
+                            test_chunk_size=chunk, **sc["render"])
+    g = render_image(f, est, rays, timestamps=T(sc["timestamps"]), test_chunk_size=chunk, **rk)
+    assert g[3] == w[3] and len(g[4]) == len(w[4])
+    for ge, we in zip(g[4], w[4]):
+        for k in ("ray_indices", "t_starts", "t_ends", "sigmas", "rgbs", "weights", "trans", "alphas"):
+            assert_bitexact(N(ge[k]), we[k], f"extras[{k}]")
+    for i, nm in enumerate(("colors", "opacities", "depths")):
+        assert g[i].shape == w[i].shape
+        assert np.abs(N(g[i]) - w[i]).max() <= 1e-4, nm
+        assert_bitexact(N(g[i]), w[i], nm)
+    if regime == "trained":
+        assert w[3] < w[5]          # the visibility filter removed something
