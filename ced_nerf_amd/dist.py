@@ -1,0 +1,104 @@
+"""Ray-parallel multi-GPU rendering: one process per GPU, rays dealt tile-cyclically, one
+all-gather of the rendered pixels per step (RCCL over xGMI when the backend is "nccl").
+
+The reference is single-GPU (train_real.py:81); SURVEY.md section 8e defines this layer.  Rays are
+independent, the field and the occupancy grid are replicated, so the only exchange step is the
+gather of [n_local, 5] float32 pixels (rgb, opacity, depth); the per-rank sample count rides in
+one extra row of the same payload, so a frame costs exactly one collective.
+"""
+from __future__ import annotations
+
+from typing import Callable, Dict, Optional
+
+import numpy as np
+import torch
+import torch.distributed as dist
+
+TILE = 8    # pixels; 8x8 tiles dealt round-robin balance the spatially clustered sample density
+
+
+def tile_cyclic_assignment(n_frames: int, height: int, width: int, world: int, tile: int = TILE):
+    """Returns (owner[n_rays] int32, per-rank lists of flat ray ids in tile-raster order)."""
+    ty = (np.arange(height) // tile)[:, None]
+    tx = (np.arange(width) // tile)[None, :]
+    tiles_x = (width + tile - 1) // tile
+    tiles_y = (height + tile - 1) // tile
+    tile_id = ty * tiles_x + tx                                         # [H,W]
+    ids = (np.arange(n_frames)[:, None, None] * (tiles_x * tiles_y) + tile_id[None]).reshape(-1)
+    owner = (ids % world).astype(np.int32)
+    order = np.argsort(ids, kind="stable")                              # tile-major ray order
+    shards = [order[owner[order] == r] for r in range(world)]
+    return owner, shards
+
+
+class ShardedRenderer:
+    """Renders a batch of frames [F,H,W] with the rays sharded over `world` ranks.
+
+    render_fn(rays_o [n,3], rays_d [n,3], timestamps) -> (rgb [n,3], opacity [n,1], depth [n,1], n_samples)
+    defaults to the HIP `render_image_test`; tests inject a CPU renderer to exercise the
+    sharding / gather / un-permute logic over gloo."""
+
+    def __init__(self, field, estimator, world: int, rank: int, device, max_samples: int = 1024,
+                 render_kwargs: Optional[Dict] = None, render_fn: Optional[Callable] = None):
+        self.field, self.estimator = field, estimator
+        self.world, self.rank, self.device = world, rank, device
+        self.max_samples = max_samples
+        self.render_kwargs = dict(render_kwargs or {})
+        self.render_fn = render_fn or self._hip_render
+        self.shape = None
+
+    def _hip_render(self, rays_o, rays_d, timestamps):
+        from .utils import Rays, render_image_test
+        return render_image_test(self.max_samples, self.field, self.estimator, Rays(rays_o, rays_d),
+                                 timestamps=timestamps, **self.render_kwargs)
+
+    def set_rays(self, origins: torch.Tensor, viewdirs: torch.Tensor) -> None:
+        assert origins.ndim == 4 and origins.shape == viewdirs.shape, "rays must be [F,H,W,3]"
+        F, H, W, _ = origins.shape
+        self.shape = (F, H, W)
+        o = origins.reshape(-1, 3); d = viewdirs.reshape(-1, 3)
+        if self.world == 1:
+            self.local_o, self.local_d = o.contiguous(), d.contiguous()
+            self.n_local = self.n_pad = o.shape[0]
+            self.gather_index = None
+            return
+        _, shards = tile_cyclic_assignment(F, H, W, self.world)
+        self.n_pad = max(len(s) for s in shards)
+        mine = shards[self.rank]
+        self.n_local = len(mine)
+        idx = np.concatenate([mine, np.repeat(mine[-1:], self.n_pad - len(mine))]) if len(mine) < self.n_pad else mine
+        idx_t = torch.from_numpy(idx.astype(np.int64)).to(o.device)
+        self.local_o = o[idx_t].contiguous()
+        self.local_d = d[idx_t].contiguous()
+        # destination (flat ray id) of every gathered row; padded rows go to a scratch slot at the end
+        n_rays = F * H * W
+        dest = np.full((self.world, self.n_pad), n_rays, np.int64)
+        for r, s in enumerate(shards):
+            dest[r, :len(s)] = s
+        self.gather_index = torch.from_numpy(dest.reshape(-1)).to(o.device)
+
+    @torch.no_grad()
+    def render(self, timestamps: torch.Tensor) -> Dict:
+        F, H, W = self.shape
+        rgb, op, dp, n_samples = self.render_fn(self.local_o, self.local_d, timestamps)
+        n_samples = int(n_samples)
+        if self.world == 1:
+            return dict(rgb=rgb.view(F, H, W, 3), opacity=op.view(F, H, W, 1), depth=dp.view(F, H, W, 1),
+                        local_samples=n_samples, total_samples=n_samples)
+        payload = torch.empty((self.n_pad + 1, 5), device=rgb.device, dtype=torch.float32)
+        payload[:-1, 0:3] = rgb.reshape(-1, 3)
+        payload[:-1, 3:4] = op.reshape(-1, 1)
+        payload[:-1, 4:5] = dp.reshape(-1, 1)
+        payload[-1].zero_()
+        payload[-1, 0] = float(n_samples >> 16)          # exact in float32: two 16-bit halves
+        payload[-1, 1] = float(n_samples & 0xFFFF)
+        gathered = torch.empty((self.world, self.n_pad + 1, 5), device=rgb.device, dtype=torch.float32)
+        dist.all_gather_into_tensor(gathered.view(-1, 5), payload)
+        tail = gathered[:, -1, :2].to(torch.float64)
+        total = int((tail[:, 0] * 65536.0 + tail[:, 1]).sum().item())
+        n_rays = F * H * W
+        image = torch.empty((n_rays + 1, 5), device=rgb.device, dtype=torch.float32)
+        image[self.gather_index] = gathered[:, :-1, :].reshape(-1, 5)
+        image = image[:n_rays]
+        return dict(rgb=image[:, 0:3].reshape(F, H, W, 3), opacity=image[:, 3:4].reshape(F, H, W, 1),
+                    depth=image[:, 4:5].reshape(F, H, W, 1), local_samples=n_samples, total_samples=total)

@@ -46,7 +46,7 @@ def sort_intersections(t_mins, t_maxs):
     """The event list of cednerf/utils.py:219-225."""
     n_rays, n_grids = t_mins.shape
     if n_grids > 1:
-        t_sorted, t_indices = torch.sort(torch.cat([t_mins, t_maxs], -1), -1, stable=True)
+        t_sorted, t_indices = torch.sort(torch.cat([t_mins, t_maxs], -1), dim=-1, stable=True)
     else:
         t_sorted = torch.cat([t_mins, t_maxs], -1)
         t_indices = torch.arange(0, n_grids * 2, device=t_mins.device, dtype=torch.int64).expand(n_rays, n_grids * 2)

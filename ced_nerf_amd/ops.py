@@ -12,7 +12,7 @@ from typing import Dict, Optional, Tuple
 import numpy as np
 import torch
 
-from . import _lib
+from . import _lib, profiling
 from .hashgrid import level_tables
 
 
@@ -113,10 +113,12 @@ def traverse_grids_raw(rays_o, rays_d, binaries, aabbs, near_planes, far_planes,
     L = _lib.lib()
     n = rays_o.shape[0]
     m, res = binaries.shape[0], binaries.shape[1]
-    rc = L.ced_traverse_grids(n, _p(rays_o), _p(rays_d), _p(_as_u8(binaries)), m, res, _p(aabbs), _p(near_planes),
-                              _p(far_planes), float(step_size), float(cone_angle), int(limit), _p(_as_u8(rays_mask)),
-                              _p(t_sorted), _p(t_indices), _p(_as_u8(hits)), int(mode), _p(base), _p(counts),
-                              _p(t_starts), _p(t_ends), _p(ray_indices), _p(termination_planes), _stream())
+    with profiling.span("traverse", n):
+        rc = L.ced_traverse_grids(n, _p(rays_o), _p(rays_d), _p(_as_u8(binaries)), m, res, _p(aabbs), _p(near_planes),
+                                  _p(far_planes), float(step_size), float(cone_angle), int(limit),
+                                  _p(_as_u8(rays_mask)), _p(t_sorted), _p(t_indices), _p(_as_u8(hits)), int(mode),
+                                  _p(base), _p(counts), _p(t_starts), _p(t_ends), _p(ray_indices),
+                                  _p(termination_planes), _stream())
     _lib.check(rc, "traverse_grids")
 
 
@@ -166,9 +168,10 @@ def field_forward_rays(desc: _lib.FieldDesc, rays_o, rays_d, ray_indices, t_star
     dev = rays_o.device
     rgb = torch.empty((n, 3), device=dev, dtype=torch.float32) if want_rgb else None
     sigma = torch.empty((n,), device=dev, dtype=torch.float32)
-    rc = _lib.lib().ced_field_forward_rays(C.byref(desc), n, _p(rays_o), _p(rays_d), _p(ray_indices), _p(t_starts),
-                                           _p(t_ends), _p(timestamps), int(bool(t_per_ray)), int(bool(want_rgb)),
-                                           _p(rgb), _p(sigma), _stream())
+    with profiling.span("field", n):
+        rc = _lib.lib().ced_field_forward_rays(C.byref(desc), n, _p(rays_o), _p(rays_d), _p(ray_indices),
+                                               _p(t_starts), _p(t_ends), _p(timestamps), int(bool(t_per_ray)),
+                                               int(bool(want_rgb)), _p(rgb), _p(sigma), _stream())
     _lib.check(rc, "field_forward_rays")
     return rgb, sigma
 
@@ -181,6 +184,8 @@ def render_weights(packed_info, t_starts, t_ends, sigmas, prefix_trans=None, wan
     _chk(t_ends, torch.float32, "t_ends"); _chk(sigmas, torch.float32, "sigmas")
     _chk(prefix_trans, torch.float32, "prefix_trans", allow_none=True)
     outs = [torch.empty_like(t_starts) if w else None for w in want]
+    if t_starts.shape[0] == 0:
+        return tuple(outs)
     rc = _lib.lib().ced_render_weights(packed_info.shape[0], _p(packed_info), _p(t_starts), _p(t_ends), _p(sigmas),
                                        _p(prefix_trans), _p(outs[0]), _p(outs[1]), _p(outs[2]), _stream())
     _lib.check(rc, "render_weights")
@@ -195,6 +200,8 @@ def accumulate_along_rays_(packed_info, weights, values, outputs):
     assert outputs.shape == (n_rays, C_)
     if values is not None:
         assert values.shape == (weights.shape[0], C_), f"Invalid shapes: {values.shape} vs {weights.shape}"
+    if weights.shape[0] == 0:
+        return outputs
     rc = _lib.lib().ced_accumulate_along_rays(n_rays, _p(packed_info), _p(weights), _p(values), C_, _p(outputs),
                                               _stream())
     _lib.check(rc, "accumulate_along_rays")
@@ -204,6 +211,8 @@ def accumulate_along_rays_(packed_info, weights, values, outputs):
 def visibility_mask(packed_info, t_starts, t_ends, sigmas, early_stop_eps, alpha_thre):
     _chk(packed_info, torch.int64, "packed_info")
     mask = torch.empty(t_starts.shape, device=t_starts.device, dtype=torch.bool)
+    if t_starts.shape[0] == 0:
+        return mask
     rc = _lib.lib().ced_visibility_mask(packed_info.shape[0], _p(packed_info), _p(t_starts), _p(t_ends), _p(sigmas),
                                         float(early_stop_eps), float(alpha_thre), _p(mask), _stream())
     _lib.check(rc, "visibility_mask")
@@ -214,8 +223,11 @@ def composite_prefix_(packed_info, t_starts, t_ends, sigmas, rgbs, rgb, opacity,
     _chk(packed_info, torch.int64, "packed_info"); _chk(rgbs, torch.float32, "rgbs")
     for nm, t in (("rgb", rgb), ("opacity", opacity), ("depth", depth)):
         _chk(t, torch.float32, nm)
-    rc = _lib.lib().ced_composite_prefix(packed_info.shape[0], _p(packed_info), _p(t_starts), _p(t_ends), _p(sigmas),
-                                         _p(rgbs), _p(rgb), _p(opacity), _p(depth), _stream())
+    if t_starts.shape[0] == 0:
+        return
+    with profiling.span("composite", t_starts.shape[0]):
+        rc = _lib.lib().ced_composite_prefix(packed_info.shape[0], _p(packed_info), _p(t_starts), _p(t_ends),
+                                             _p(sigmas), _p(rgbs), _p(rgb), _p(opacity), _p(depth), _stream())
     _lib.check(rc, "composite_prefix")
 
 

@@ -126,7 +126,8 @@ def test_hash_encode(oracle, max_res, log2T, dtype, temporal):
     t = np.random.default_rng(4).uniform(0, 1, size=x.shape[0]).astype(np.float32)
     t[:3] = [0.0, 1.0, 1.0 / 3.0]
     want = of.hash_encode(x, t if temporal else None)
-    desc, _ = ops.make_hash_desc(T(p["hash"]["table"]), 16, max_res, 16, log2T, temporal)
+    table = T(p["hash"]["table"])      # the descriptor holds a raw pointer: keep the tensor alive
+    desc, _ = ops.make_hash_desc(table, 16, max_res, 16, log2T, temporal)
     got = ops.hash_encode(desc, T(x), T(t) if temporal else None)
     assert_bitexact(N(got), want, "hash features")
     assert np.abs(want).max() > 0.1
