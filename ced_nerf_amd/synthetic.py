@@ -122,8 +122,9 @@ def init_field_params(aabb, moving_step: float, hash_max_res: int = 1024, log2_h
     """Deterministic DNGPradianceField parameters (model.py:100-309 dims; SURVEY 8d regimes).
 
     regime "init": hash U(-1e-4,1e-4) (hash_encoder_half.py:313), Xavier-uniform bias-free MLPs.
-    regime "trained": hash N(0,0.5^2), mlp_base output row 0 (density) scaled x8 so sigma spans
-    0..1e3 and rays terminate early, as in a trained scene."""
+    regime "trained": hash N(0,0.5^2), mlp_base output row 0 (density) scaled x32 so sigma spans
+    0..1e3 and rays terminate early, as in a trained scene; mlp_head output scaled x16 so colours
+    use the whole (0,1) range."""
     rng = np.random.default_rng(seed)
     total = hash_total_entries(base_res, hash_max_res, n_levels, log2_hashmap_size)
     width = 8 if temporal_hash else 2
@@ -143,7 +144,8 @@ def init_field_params(aabb, moving_step: float, hash_max_res: int = 1024, log2_h
     mlp_base = [_xavier(rng, 64, base_in), _xavier(rng, 16, 64)]
     mlp_head = [_xavier(rng, 64, 19), _xavier(rng, 64, 64), _xavier(rng, 3, 64)]
     if regime == "trained":
-        mlp_base[1][0, :] *= np.float32(8.0)
+        mlp_base[1][0, :] *= np.float32(32.0)
+        mlp_head[2] *= np.float32(16.0)
     return dict(aabb=np.asarray(aabb, np.float32), moving_step=float(moving_step),
                 use_div_offsets=bool(use_div_offsets), time_mode=time_mode,
                 hash=dict(base_res=base_res, max_res=hash_max_res, n_levels=n_levels,
