@@ -1,0 +1,152 @@
+"""CPU suite, part 2: the C-ABI library and the host logic (no kernel is launched here)."""
+import ctypes as C
+import os
+
+import numpy as np
+import pytest
+import torch
+
+
+def test_library_exports_every_declared_symbol():
+    from ced_nerf_amd import _lib
+    names = _lib.header_symbols()
+    assert len(names) >= 15 and set(names) == set(_lib.PROTOTYPES), set(names) ^ set(_lib.PROTOTYPES)
+    raw = C.CDLL(_lib.LIB_PATH)
+    for n in names:
+        assert hasattr(raw, n), f"{n} declared in include/cednerf_hip.h but not exported"
+    L = _lib.lib()
+    assert L.ced_version() == 1
+
+
+def test_struct_layout_matches_header():
+    from ced_nerf_amd import _lib
+    assert C.sizeof(_lib.HashDesc) == 16 + 5 * 64 + 8 + 8
+    assert C.sizeof(_lib.FieldDesc) == 24 + 4 + 3 * 4 + 8 + 8 + C.sizeof(_lib.HashDesc)
+    assert _lib.FieldDesc.hash.offset == 56
+
+
+def test_argument_errors_are_reported_not_thrown():
+    from ced_nerf_amd import _lib
+    L = _lib.lib()
+    rc = L.ced_ray_aabb_intersect(-1, None, None, 1, None, 0.0, 1.0, 1.0, None, None, None, None)
+    assert rc == -1 and b"ray_aabb_intersect" in L.ced_last_error_string()
+    rc = L.ced_ray_aabb_intersect(5, None, None, 1, None, 0.0, 1.0, 1.0, None, None, None, None)
+    assert rc == -1 and b"null pointer" in L.ced_last_error_string()
+    assert L.ced_ray_aabb_intersect(0, None, None, 1, None, 0.0, 1.0, 1.0, None, None, None, None) == 0   # empty input
+    rc = L.ced_traverse_grids(4, None, None, None, 1, 128, None, None, None, 1e-3, 0.0, 0, None, None, None, None, 7,
+                              None, None, None, None, None, None, None)
+    assert rc == -1 and b"mode" in L.ced_last_error_string()
+    assert L.ced_accumulate_along_rays(3, None, None, None, 3, None, None) == -1
+    with pytest.raises(RuntimeError, match="accumulate_along_rays"):
+        _lib.check(-1, "accumulate_along_rays")
+    d = _lib.FieldDesc()
+    d.hash.n_levels = 12
+    assert L.ced_field_forward(C.byref(d), 4, 1, 1, None, None, 1, None, None) != 0
+    assert L.ced_field_forward(C.byref(d), 0, None, None, None, None, None, None, None) == 0            # n == 0
+
+
+def _ref_pack(layer_w, n_out_rows, ks, rot=0):
+    """Independent numpy statement of the fragment order: [nb][q][lane][s]."""
+    w = np.asarray(layer_w, np.float32)
+    nb = (n_out_rows + 15) // 16
+    ks4 = (ks + 3) // 4
+    out = np.zeros((nb, ks4, 64, 4), np.float32)
+    for p in range(nb * 16):
+        neuron = (p + rot) % 16 if rot else p
+        if neuron >= w.shape[0]:
+            continue
+        for k in range(min(w.shape[1], ks * 4)):
+            S, kk = divmod(k, 4)
+            out[p // 16, S // 4, kk * 16 + p % 16, S % 4] = w[neuron, k]
+    return out.reshape(-1)
+
+
+@pytest.mark.parametrize("div,tm", [(0, 0), (1, 0), (0, 1), (1, 2)])
+def test_pack_field_weights_layout(div, tm):
+    from ced_nerf_amd import ops, synthetic as S
+    p = S.init_field_params([-1, -1, -1, 1, 1, 1], 1e-3, 1024, 10, use_div_offsets=bool(div),
+                            use_time_embedding=tm > 0, use_time_attenuation=tm == 2)
+    blob = ops.pack_field_weights(bool(div), tm, p["xyz_wrap"], p["mlp_base"], p["mlp_head"])
+    ksb0 = 11 if tm else 8
+    parts = [_ref_pack(p["xyz_wrap"][0], 64, 8), _ref_pack(p["xyz_wrap"][1], 64, 16), _ref_pack(p["xyz_wrap"][2], 64, 16),
+             _ref_pack(p["xyz_wrap"][3], 16, 16), _ref_pack(p["mlp_base"][0], 64, ksb0),
+             _ref_pack(p["mlp_base"][1], 16, 16, rot=13), _ref_pack(p["mlp_head"][0], 64, 5),
+             _ref_pack(p["mlp_head"][1], 64, 16), _ref_pack(p["mlp_head"][2], 16, 16)]
+    want = np.concatenate(parts)
+    assert blob.shape == want.shape == ((22528 if tm else 21504),)
+    assert np.array_equal(blob, want)
+    # every weight appears exactly once
+    nz = sum(int(np.count_nonzero(w)) for w in p["xyz_wrap"] + p["mlp_base"] + p["mlp_head"])
+    assert np.count_nonzero(blob) == nz
+    with pytest.raises(ValueError):
+        ops.pack_field_weights(bool(div), tm, p["xyz_wrap"][:3] + [np.zeros((5, 64), np.float32)], p["mlp_base"], p["mlp_head"])
+
+
+def test_level_tables_match_survey():
+    from ced_nerf_amd.hashgrid import level_tables
+    for max_res, total, first_hashed in ((1024, 19263424, 8), (4096, 22565520, 6), (8192, 23928800, 6)):
+        t = level_tables(16, max_res, 16, 21)
+        assert t["total"] == total and int(np.argmax(t["hashed"])) == first_hashed and int(t["res"][-1]) == max_res
+        assert t["scale"][0] == 15.0 and t["scale"][-1] == max_res - 1
+        assert all(int(s) % 8 == 0 for s in t["size"])
+    with pytest.raises(ValueError):
+        level_tables(16, 1024, 17, 21)
+
+
+def test_ops_reject_cpu_tensors_and_bad_shapes():
+    """The product path has no CPU fallback: host tensors are refused like cednerf/render.py:17-18."""
+    from ced_nerf_amd import nerfacc_api as A, ops
+    from ced_nerf_amd.render import reduce_along_rays
+    o = torch.zeros(4, 3); d = torch.ones(4, 3); ab = torch.tensor([[-1., -1, -1, 1, 1, 1]])
+    with pytest.raises(NotImplementedError, match="Only support cuda inputs"):
+        A.ray_aabb_intersect(o, d, ab)
+    with pytest.raises(NotImplementedError, match="Only support cuda inputs"):
+        reduce_along_rays(torch.zeros(3, dtype=torch.long), torch.zeros(3, 2))
+    with pytest.raises(NotImplementedError, match="Only support cuda inputs"):
+        ops.render_weights(torch.zeros(2, 2, dtype=torch.long), torch.zeros(3), torch.zeros(3), torch.zeros(3))
+    with pytest.raises(ValueError):
+        ops.make_hash_desc(torch.zeros(10, 2), 16, 1024, 16, 21)
+
+
+def test_field_module_construction_and_guards():
+    from ced_nerf_amd import synthetic as S
+    from ced_nerf_amd.model import DNGPradianceField, DNGPRadianceField
+    assert DNGPRadianceField is DNGPradianceField
+    p = S.init_field_params([-1, -1, -1, 1, 1, 1], 1e-3, 1024, 10, use_time_embedding=True)
+    f = DNGPradianceField.from_params(p, "cpu")
+    assert f.hash_table.shape[1] == 2 and f.mlp_base[0].shape == (64, 41) and f.aabb.shape == (6,)
+    q = f.export_params()
+    assert np.array_equal(q["mlp_head"][2], p["mlp_head"][2]) and q["time_mode"] == 1
+    with pytest.raises(NotImplementedError, match="cuda"):
+        f(torch.zeros(2, 3), torch.zeros(2, 1), torch.ones(2, 3))
+    g = DNGPradianceField([-1, -1, -1, 1, 1, 1], dst_resolution=1024, log2_hashmap_size=10, seed=1)
+    assert abs(float(g.hash_table.abs().max())) <= 1e-4 and g.mlp_base[0].shape == (64, 32)
+    for bad in (dict(n_levels=8), dict(hash4motion=True), dict(use_feat_predict=True), dict(geo_feat_dim=7)):
+        with pytest.raises(NotImplementedError):
+            DNGPradianceField([-1, -1, -1, 1, 1, 1], log2_hashmap_size=10, **bad)
+
+
+def test_estimator_state_and_api_names():
+    import ced_nerf_amd as cednerf
+    from ced_nerf_amd.nerfacc_api import OccGridEstimator
+    est = OccGridEstimator([-1, -1, -1, 1, 1, 1], 128, 2)
+    assert est.binaries.shape == (2, 128, 128, 128) and est.binaries.dtype == torch.bool
+    assert est.aabbs.shape == (2, 6) and est.aabbs[1].tolist() == [-2, -2, -2, 2, 2, 2] and est.occs.shape == (2 * 128 ** 3,)
+    assert cednerf.utils.render_image_with_occgrid is cednerf.utils.render_image
+    for name in ("render_image", "render_image_test", "trunc_exp", "set_random_seed", "Rays", "namedtuple_map"):
+        assert hasattr(cednerf.utils, name)
+    for name in ("rendering", "reduce_along_rays", "render_weight_from_density_prefix"):
+        assert hasattr(cednerf.render, name)
+    assert torch.allclose(cednerf.utils.trunc_exp(torch.tensor([0.0, 1.0]).half()), torch.tensor([1.0, 2.7182817]))
+
+
+def test_synthetic_scene_is_deterministic_and_lego_like():
+    from ced_nerf_amd import synthetic as S
+    a = S.make_scene("dnerf", 40, 30, "trained", log2_hashmap_size=12)
+    b = S.make_scene("dnerf", 40, 30, "trained", log2_hashmap_size=12)
+    assert np.array_equal(a["origins"], b["origins"]) and np.array_equal(a["params"]["hash"]["table"], b["params"]["hash"]["table"])
+    assert 0.02 < a["binaries"].mean() < 0.08
+    assert np.allclose(np.linalg.norm(a["viewdirs"], axis=-1), 1.0, atol=1e-6)
+    assert np.allclose(np.linalg.norm(a["origins"], axis=-1), 4.0, atol=1e-5)
+    h = S.make_scene("hypernerf", 24, 32, "init", log2_hashmap_size=12)
+    assert h["binaries"].shape[0] == 2 and h["params"]["time_mode"] == 2 and h["params"]["use_div_offsets"]
