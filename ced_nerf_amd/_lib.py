@@ -48,15 +48,16 @@ PROTOTYPES = {
     "ced_pack_field_weights": (C.c_int, [C.c_int, C.c_int] + [_vp] * 10),
     "ced_ray_aabb_intersect": (C.c_int, [_i64, _vp, _vp, _i32, _vp, _f, _f, _f, _vp, _vp, _vp, _vp]),
     "ced_traverse_grids": (C.c_int, [_i64, _vp, _vp, _vp, _i32, _i32, _vp, _vp, _vp, _f, _f, _i32, _vp, _vp, _vp, _vp,
-                                     _i32, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
+                                     _i32, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "ced_hash_encode": (C.c_int, [C.POINTER(HashDesc), _i64, _vp, _vp, _vp, _vp]),
     "ced_field_forward": (C.c_int, [C.POINTER(FieldDesc), _i64, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
-    "ced_field_forward_rays": (C.c_int, [C.POINTER(FieldDesc), _i64, _vp, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _vp,
-                                         _vp, _vp]),
+    "ced_field_forward_rays": (C.c_int, [C.POINTER(FieldDesc), _i64, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i32, _i32,
+                                         _vp, _vp, _vp]),
     "ced_render_weights": (C.c_int, [_i64, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "ced_accumulate_along_rays": (C.c_int, [_i64, _vp, _vp, _vp, _i32, _vp, _vp]),
     "ced_visibility_mask": (C.c_int, [_i64, _vp, _vp, _vp, _vp, _f, _f, _vp, _vp]),
     "ced_composite_prefix": (C.c_int, [_i64, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "ced_composite_step": (C.c_int, [_i64, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _f, _i32, _vp, _vp, _vp]),
     "ced_composite_test": (C.c_int, [_i64, _vp, _vp, _vp, _vp, _vp, _vp, _f, _f, _vp, _vp, _vp, _vp]),
     "ced_finalize_pixels": (C.c_int, [_i64, _vp, _vp, _vp, _vp, _vp]),
 }

@@ -104,6 +104,59 @@ __global__ __launch_bounds__(256) void composite_prefix_kernel(int64_t n_rays, c
     depth[r] = dp;
 }
 
+// composite_prefix + the ray bookkeeping of cednerf/utils.py:301-307 (mask update, alive count, sample count)
+__global__ __launch_bounds__(256) void composite_step_kernel(int64_t n_rays, const int64_t *__restrict__ packed,
+                                                             const float *__restrict__ t0, const float *__restrict__ t1,
+                                                             const float *__restrict__ sig,
+                                                             const float *__restrict__ rgbs, float *__restrict__ rgb,
+                                                             float *__restrict__ opacity, float *__restrict__ depth,
+                                                             float opc_thres, int n_samples_iter,
+                                                             uint8_t *__restrict__ ray_mask,
+                                                             unsigned long long *__restrict__ stats)
+{
+    int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    int64_t cnt = 0;
+    bool alive = false;
+    if (r < n_rays) {
+        int64_t s0 = packed[2 * r];
+        cnt = packed[2 * r + 1];
+        float op = opacity[r];
+        if (cnt > 0) {
+            const float prefix = 1.0f - op;
+            float c0 = rgb[3 * r], c1 = rgb[3 * r + 1], c2 = rgb[3 * r + 2], dp = depth[r];
+            float acc = 0.0f;
+            for (int64_t i = s0; i < s0 + cnt; ++i) {
+                float ts = t0[i], te = t1[i];
+                float sd = sig[i] * (te - ts);
+                float a = 1.0f - det_expf(-sd);
+                float t = det_expf(-acc) * prefix;
+                float w = t * a;
+                c0 = c0 + w * rgbs[3 * i];
+                c1 = c1 + w * rgbs[3 * i + 1];
+                c2 = c2 + w * rgbs[3 * i + 2];
+                op = op + w;
+                dp = dp + w * ((ts + te) / 2.0f);
+                acc = acc + sd;
+            }
+            rgb[3 * r] = c0; rgb[3 * r + 1] = c1; rgb[3 * r + 2] = c2;
+            opacity[r] = op;
+            depth[r] = dp;
+        }
+        alive = (op <= opc_thres) && (cnt == (int64_t)n_samples_iter);
+        ray_mask[r] = alive ? 1 : 0;
+    }
+    // wave-level reduction, one atomic pair per wave
+    const unsigned long long ballot = __ballot(alive);
+    int c = (int)cnt;
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) c += __shfl_down(c, off, 64);
+    if ((threadIdx.x & 63) == 0) {
+        const int n_alive = __builtin_popcountll(ballot);
+        if (n_alive) atomicAdd(&stats[0], (unsigned long long)n_alive);
+        if (c) atomicAdd(&stats[1], (unsigned long long)c);
+    }
+}
+
 __global__ __launch_bounds__(256) void composite_test_kernel(int64_t n_alive, const float *__restrict__ sigmas,
                                                              const float *__restrict__ rgbs,
                                                              const float *__restrict__ t_start,
@@ -207,6 +260,20 @@ extern "C" int ced_composite_prefix(int64_t n_rays, const int64_t *packed_info, 
     hipLaunchKernelGGL(ced::composite_prefix_kernel, ced::grid_for(n_rays), dim3(256), 0, (hipStream_t)stream, n_rays,
                        packed_info, t_starts, t_ends, sigmas, rgbs, rgb, opacity, depth);
     return ced::check_launch("composite_prefix");
+}
+
+extern "C" int ced_composite_step(int64_t n_rays, const int64_t *packed_info, const float *t_starts,
+                                  const float *t_ends, const float *sigmas, const float *rgbs, float *rgb,
+                                  float *opacity, float *depth, float opc_thres, int32_t n_samples_iter,
+                                  uint8_t *ray_mask, int64_t *stats, void *stream)
+{
+    CED_REQUIRE(n_rays >= 0, "composite_step: n_rays < 0");
+    if (n_rays == 0) return CED_OK;
+    CED_REQUIRE(packed_info && rgb && opacity && depth && ray_mask && stats, "composite_step: null pointer");
+    hipLaunchKernelGGL(ced::composite_step_kernel, ced::grid_for(n_rays), dim3(256), 0, (hipStream_t)stream, n_rays,
+                       packed_info, t_starts, t_ends, sigmas, rgbs, rgb, opacity, depth, opc_thres,
+                       (int)n_samples_iter, ray_mask, reinterpret_cast<unsigned long long *>(stats));
+    return ced::check_launch("composite_step");
 }
 
 extern "C" int ced_composite_test(int64_t n_alive, const float *sigmas, const float *rgbs, const float *t_start,

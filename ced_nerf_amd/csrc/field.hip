@@ -48,6 +48,7 @@ constexpr int kMaxBlobFloats = Blob<true>::TOTAL;
 
 struct FieldArgs {
     int64_t n;
+    const int64_t *n_dev;                             // optional device-side sample count (<= n)
     const float *pos, *t, *dir;                       // explicit mode
     const float *rays_o, *rays_d;                     // rays mode
     const int64_t *ray_idx;
@@ -286,7 +287,12 @@ __global__ __launch_bounds__(FIELD_THREADS, 2) void field_kernel(FieldArgs A)
         LC[i].hashed = lt[5];
     }
 
-    const int64_t n_tiles = (A.n + 63) / 64;
+    int64_t n_eff = A.n;
+    if (A.n_dev) {
+        const int64_t nd = *A.n_dev;
+        n_eff = nd < n_eff ? nd : n_eff;
+    }
+    const int64_t n_tiles = (n_eff + 63) / 64;
     const float extent[3] = { A.aabb[3] - A.aabb[0], A.aabb[4] - A.aabb[1], A.aabb[5] - A.aabb[2] };
 
     for (int64_t tile = (int64_t)blockIdx.x * FIELD_WAVES + wave; tile < n_tiles;
@@ -297,7 +303,7 @@ __global__ __launch_bounds__(FIELD_THREADS, 2) void field_kernel(FieldArgs A)
 #pragma unroll
         for (int j = 0; j < NT; ++j) {
             int64_t s = tile * 64 + 16 * j + c;
-            s = s < A.n ? s : A.n - 1;
+            s = s < n_eff ? s : n_eff - 1;
             sidx[j] = s;
             if (A.rays_mode) {
                 const int64_t r = A.ray_idx[s];
@@ -398,8 +404,8 @@ __global__ __launch_bounds__(FIELD_THREADS, 2) void field_kernel(FieldArgs A)
             const int64_t s = tile * 64 + 16 * j + c;
             float sg = det_expf(D[j][0][3] - 1.0f);           // density = trunc_exp(raw - 1) * selector
             sg = sel[j] ? sg : 0.0f;
-            if (store_lane && s < A.n) A.sigma[s] = sg;
-            if (A.geo && s < A.n) {
+            if (store_lane && s < n_eff) A.sigma[s] = sg;
+            if (A.geo && s < n_eff) {
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
                     const int nidx = (4 * g + r + 13) & 15;
@@ -443,7 +449,7 @@ __global__ __launch_bounds__(FIELD_THREADS, 2) void field_kernel(FieldArgs A)
                 float o3[3];
 #pragma unroll
                 for (int a = 0; a < 3; ++a) o3[a] = 1.0f / (1.0f + det_expf(-D[j][0][a]));
-                if (store_lane && s < A.n) {
+                if (store_lane && s < n_eff) {
                     A.rgb[3 * s] = o3[0];
                     A.rgb[3 * s + 1] = o3[1];
                     A.rgb[3 * s + 2] = o3[2];
@@ -626,8 +632,8 @@ extern "C" int ced_field_forward(const ced_field_desc *desc, int64_t n, const fl
     return ced::launch_field(desc, A, stream);
 }
 
-extern "C" int ced_field_forward_rays(const ced_field_desc *desc, int64_t n, const float *rays_o, const float *rays_d,
-                                      const int64_t *ray_indices, const float *t_starts, const float *t_ends,
+extern "C" int ced_field_forward_rays(const ced_field_desc *desc, int64_t n, const int64_t *n_dev,
+                                      const float *rays_o, const float *rays_d, const int64_t *ray_indices, const float *t_starts, const float *t_ends,
                                       const float *timestamps, int32_t t_per_ray, int32_t want_rgb, float *rgb,
                                       float *sigma, void *stream)
 {
@@ -639,6 +645,7 @@ extern "C" int ced_field_forward_rays(const ced_field_desc *desc, int64_t n, con
     CED_REQUIRE(!want_rgb || rgb, "field_forward_rays: want_rgb without an rgb buffer");
     ced::FieldArgs A{};
     A.n = n;
+    A.n_dev = n_dev;
     A.rays_o = rays_o; A.rays_d = rays_d; A.ray_idx = ray_indices;
     A.t0 = t_starts; A.t1 = t_ends; A.timestamps = timestamps;
     A.rays_mode = 1; A.t_per_ray = t_per_ray ? 1 : 0; A.want_rgb = want_rgb ? 1 : 0;

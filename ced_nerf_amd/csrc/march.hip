@@ -55,6 +55,18 @@ __device__ __forceinline__ float calc_dt(float t, float cone_angle, float dt_min
     float v = t * cone_angle;
     return __builtin_fminf(__builtin_fmaxf(v, dt_min), dt_max);
 }
+// march t_last forward in whole steps until the next step's mid-point reaches `target`
+__device__ __forceinline__ float skip_march(float t_last, float target, float step_size, float cone_angle)
+{
+    if (step_size <= 0.0f) return target;
+    for (;;) {
+        float dt = calc_dt(t_last, cone_angle, step_size, 1e10f);
+        if (t_last + dt * 0.5f >= target) break;
+        t_last += dt;
+    }
+    return t_last;
+}
+constexpr int kLook = 4;
 __device__ __forceinline__ int clampi(int v, int lo, int hi) { return v < lo ? lo : (v > hi ? hi : v); }
 
 struct TraverseArgs {
@@ -76,6 +88,7 @@ struct TraverseArgs {
     float *t_starts, *t_ends;
     int64_t *ray_indices;
     float *termination_planes;
+    int64_t *packed_info_out;
 };
 
 __global__ __launch_bounds__(256) void traverse_kernel(TraverseArgs A)
@@ -83,9 +96,14 @@ __global__ __launch_bounds__(256) void traverse_kernel(TraverseArgs A)
     int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (r >= A.n_rays) return;
     const float near = A.near_planes[r], far = A.far_planes[r];
+    int64_t out_base = 0;
+    if (A.mode == 1) out_base = A.base[r];
+    else if (A.mode == 2) out_base = r * (int64_t)A.limit;
+    else if (A.mode == 3) out_base = A.base[r] - A.counts[r];      // base = inclusive scan of the counts
     if (A.rays_mask && !A.rays_mask[r]) {
         A.counts[r] = 0;
         if (A.termination_planes) A.termination_planes[r] = near;
+        if (A.packed_info_out) { A.packed_info_out[2 * r] = out_base; A.packed_info_out[2 * r + 1] = 0; }
         return;
     }
     const float eps = 1e-6f;
@@ -98,10 +116,7 @@ __global__ __launch_bounds__(256) void traverse_kernel(TraverseArgs A)
     const float *ts_row = A.t_sorted + r * 2 * n_grids;
     const int64_t *ti_row = A.t_indices + r * 2 * n_grids;
     const uint8_t *hit_row = A.hits + r * n_grids;
-    int64_t out_base = 0;
     const bool fill = A.mode != 0;
-    if (A.mode == 1) out_base = A.base[r];
-    else if (A.mode == 2) out_base = r * (int64_t)limit;
 
     float t_last = near;
     bool continuous = false;
@@ -120,17 +135,7 @@ __global__ __launch_bounds__(256) void traverse_kernel(TraverseArgs A)
         float this_tmin = __builtin_fmaxf(ts_row[i], near);
         float this_tmax = __builtin_fminf(ts_row[i + 1], far);
         if (this_tmin >= this_tmax) continue;
-        if (!continuous) {
-            if (step_size <= 0.0f) {
-                t_last = this_tmin;
-            } else {
-                for (;;) {
-                    float dt = calc_dt(t_last, cone_angle, step_size, 1e10f);
-                    if (t_last + dt * 0.5f >= this_tmin) break;
-                    t_last += dt;
-                }
-            }
-        }
+        if (!continuous) t_last = skip_march(t_last, this_tmin, step_size, cone_angle);
         const float *ab = A.aabbs + 6 * lvl;
         float tdist[3], delta[3];
         int cur[3], stp[3], ovf[3];
@@ -152,21 +157,56 @@ __global__ __launch_bounds__(256) void traverse_kernel(TraverseArgs A)
             ovf[a] = fin + stp[a];
         }
         const uint8_t *grid = A.binaries + (int64_t)lvl * res * res * res;
-        while (limit <= 0 || n < limit) {
-            float t_trav = __builtin_fminf(__builtin_fminf(tdist[0], __builtin_fminf(tdist[1], tdist[2])), this_tmax);
-            int64_t cell = ((int64_t)cur[0] * res + cur[1]) * res + cur[2];
-            if (!grid[cell]) {
-                if (step_size <= 0.0f) {
-                    t_last = t_trav;
-                } else {
-                    for (;;) {
-                        float dt = calc_dt(t_last, cone_angle, step_size, 1e10f);
-                        if (t_last + dt * 0.5f >= t_trav) break;
-                        t_last += dt;
+        // The DDA path does not depend on the occupancy values, so it runs kLook cells ahead and the
+        // occupancy bytes of those cells are fetched together (one dependent-load latency per kLook
+        // cells instead of per cell).  Runs of empty cells only remember the farthest boundary; the
+        // skip-march to it happens once, before the next occupied cell or at the end -- the same
+        // t_last sequence as marching cell by cell, because the recurrence t_last += dt does not
+        // depend on where the intermediate boundaries are.
+        bool dda_done = false, stop = false, has_pending = false;
+        float pending = 0.0f;
+        while (!dda_done && !stop) {
+            float tt[kLook];
+            int64_t cellv[kLook];
+            bool valid[kLook];
+#pragma unroll
+            for (int b = 0; b < kLook; ++b) {
+                valid[b] = !dda_done;
+                tt[b] = __builtin_fminf(__builtin_fminf(tdist[0], __builtin_fminf(tdist[1], tdist[2])), this_tmax);
+                cellv[b] = ((int64_t)cur[0] * res + cur[1]) * res + cur[2];
+                if (!dda_done) {
+                    int ax;
+                    if (tdist[0] < tdist[1] && tdist[0] < tdist[2]) ax = 0;
+                    else if (tdist[1] < tdist[2]) ax = 1;
+                    else ax = 2;
+#pragma unroll
+                    for (int a = 0; a < 3; ++a) {
+                        if (a == ax) {
+                            cur[a] += stp[a];
+                            tdist[a] += delta[a];
+                            dda_done = (cur[a] == ovf[a]);
+                        }
                     }
                 }
-                continuous = false;
-            } else {
+            }
+            uint8_t occ[kLook];
+#pragma unroll
+            for (int b = 0; b < kLook; ++b) occ[b] = valid[b] ? grid[cellv[b]] : (uint8_t)0;
+#pragma unroll
+            for (int b = 0; b < kLook; ++b) {
+                if (!valid[b] || stop) continue;
+                if (limit > 0 && n >= limit) { stop = true; continue; }
+                const float t_trav = tt[b];
+                if (!occ[b]) {
+                    pending = t_trav;
+                    has_pending = true;
+                    continuous = false;
+                    continue;
+                }
+                if (has_pending) {
+                    t_last = skip_march(t_last, pending, step_size, cone_angle);
+                    has_pending = false;
+                }
                 while (limit <= 0 || n < limit) {
                     float t_next;
                     if (step_size <= 0.0f) {
@@ -187,25 +227,12 @@ __global__ __launch_bounds__(256) void traverse_kernel(TraverseArgs A)
                     if (t_next >= t_trav) break;
                 }
             }
-            int ax;
-            if (tdist[0] < tdist[1] && tdist[0] < tdist[2]) ax = 0;
-            else if (tdist[1] < tdist[2]) ax = 1;
-            else ax = 2;
-            // branch-free select keeps cur/tdist in registers
-            bool done = false;
-#pragma unroll
-            for (int a = 0; a < 3; ++a) {
-                if (a == ax) {
-                    cur[a] += stp[a];
-                    tdist[a] += delta[a];
-                    done = (cur[a] == ovf[a]);
-                }
-            }
-            if (done) break;
         }
+        if (has_pending) t_last = skip_march(t_last, pending, step_size, cone_angle);
     }
     A.counts[r] = n;
     if (A.termination_planes) A.termination_planes[r] = t_last;
+    if (A.packed_info_out) { A.packed_info_out[2 * r] = out_base; A.packed_info_out[2 * r + 1] = n; }
 }
 
 }  // namespace ced
@@ -230,19 +257,21 @@ extern "C" int ced_traverse_grids(int64_t n_rays, const float *rays_o, const flo
                                   const uint8_t *rays_mask, const float *t_sorted, const int64_t *t_indices,
                                   const uint8_t *hits, int32_t mode, const int64_t *base, int64_t *counts,
                                   float *t_starts, float *t_ends, int64_t *ray_indices, float *termination_planes,
-                                  void *stream)
+                                  int64_t *packed_info_out, void *stream)
 {
     CED_REQUIRE(n_rays >= 0 && n_grids >= 1 && res >= 1, "traverse_grids: bad sizes");
-    CED_REQUIRE(mode >= 0 && mode <= 2, "traverse_grids: mode must be 0 (count), 1 (fill) or 2 (over-allocate)");
+    CED_REQUIRE(mode >= 0 && mode <= 3,
+                "traverse_grids: mode must be 0 (count), 1 (fill), 2 (over-allocate) or 3 (fill, inclusive scan)");
     if (n_rays == 0) return CED_OK;
     CED_REQUIRE(rays_o && rays_d && binaries && aabbs && near_planes && far_planes && t_sorted && t_indices && hits &&
                     counts,
                 "traverse_grids: null pointer");
-    if (mode == 1) CED_REQUIRE(base && t_starts && t_ends, "traverse_grids: fill mode needs base/t_starts/t_ends");
+    if (mode == 1 || mode == 3)
+        CED_REQUIRE(base && t_starts && t_ends, "traverse_grids: fill mode needs base/t_starts/t_ends");
     if (mode == 2) CED_REQUIRE(limit > 0 && t_starts && t_ends, "traverse_grids: over-allocate needs limit > 0");
     ced::TraverseArgs A{ n_rays, rays_o, rays_d, binaries, n_grids, res, aabbs, near_planes, far_planes, step_size,
                          cone_angle, limit, rays_mask, t_sorted, t_indices, hits, mode, base, counts, t_starts,
-                         t_ends, ray_indices, termination_planes };
+                         t_ends, ray_indices, termination_planes, packed_info_out };
     dim3 block(256), grid((unsigned)((n_rays + 255) / 256));
     hipLaunchKernelGGL(ced::traverse_kernel, grid, block, 0, (hipStream_t)stream, A);
     return ced::check_launch("traverse_grids");

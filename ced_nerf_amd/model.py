@@ -207,11 +207,12 @@ class DNGPradianceField(torch.nn.Module):
 
     # fused closures of the render drivers (cednerf/utils.py:74-104,181-195)
     @torch.no_grad()
-    def query_rays(self, rays_o, rays_d, ray_indices, t_starts, t_ends, timestamps, want_rgb: bool = True):
+    def query_rays(self, rays_o, rays_d, ray_indices, t_starts, t_ends, timestamps, want_rgb: bool = True,
+                   n_dev: Optional[torch.Tensor] = None):
         ts = timestamps.reshape(-1).float().contiguous()
         per_ray = bool(self.training)
         return ops.field_forward_rays(self._descriptor(), rays_o, rays_d, ray_indices, t_starts, t_ends, ts, per_ray,
-                                      want_rgb)
+                                      want_rgb, n_dev=n_dev)
 
 
 # spelling used by BASELINE.json's north_star

@@ -109,7 +109,7 @@ def ray_aabb_intersect(rays_o, rays_d, aabbs, near_plane=-float("inf"), far_plan
 
 def traverse_grids_raw(rays_o, rays_d, binaries, aabbs, near_planes, far_planes, step_size, cone_angle, limit,
                        rays_mask, t_sorted, t_indices, hits, mode, base=None, counts=None, t_starts=None,
-                       t_ends=None, ray_indices=None, termination_planes=None):
+                       t_ends=None, ray_indices=None, termination_planes=None, packed_info_out=None):
     L = _lib.lib()
     n = rays_o.shape[0]
     m, res = binaries.shape[0], binaries.shape[1]
@@ -118,7 +118,7 @@ def traverse_grids_raw(rays_o, rays_d, binaries, aabbs, near_planes, far_planes,
                                   _p(far_planes), float(step_size), float(cone_angle), int(limit),
                                   _p(_as_u8(rays_mask)), _p(t_sorted), _p(t_indices), _p(_as_u8(hits)), int(mode),
                                   _p(base), _p(counts), _p(t_starts), _p(t_ends), _p(ray_indices),
-                                  _p(termination_planes), _stream())
+                                  _p(termination_planes), _p(packed_info_out), _stream())
     _lib.check(rc, "traverse_grids")
 
 
@@ -156,7 +156,8 @@ def field_forward(desc: _lib.FieldDesc, positions, t, directions=None, want_geo=
 
 
 def field_forward_rays(desc: _lib.FieldDesc, rays_o, rays_d, ray_indices, t_starts, t_ends, timestamps,
-                       t_per_ray: bool, want_rgb: bool):
+                       t_per_ray: bool, want_rgb: bool, n_dev: Optional[torch.Tensor] = None):
+    """n_dev: optional device int64 scalar; the kernel evaluates min(len(ray_indices), n_dev) samples."""
     _chk(rays_o, torch.float32, "rays_o"); _chk(rays_d, torch.float32, "rays_d")
     _chk(ray_indices, torch.int64, "ray_indices")
     _chk(t_starts, torch.float32, "t_starts"); _chk(t_ends, torch.float32, "t_ends")
@@ -169,7 +170,7 @@ def field_forward_rays(desc: _lib.FieldDesc, rays_o, rays_d, ray_indices, t_star
     rgb = torch.empty((n, 3), device=dev, dtype=torch.float32) if want_rgb else None
     sigma = torch.empty((n,), device=dev, dtype=torch.float32)
     with profiling.span("field", n):
-        rc = _lib.lib().ced_field_forward_rays(C.byref(desc), n, _p(rays_o), _p(rays_d), _p(ray_indices),
+        rc = _lib.lib().ced_field_forward_rays(C.byref(desc), n, _p(n_dev), _p(rays_o), _p(rays_d), _p(ray_indices),
                                                _p(t_starts), _p(t_ends), _p(timestamps), int(bool(t_per_ray)),
                                                int(bool(want_rgb)), _p(rgb), _p(sigma), _stream())
     _lib.check(rc, "field_forward_rays")
@@ -229,6 +230,20 @@ def composite_prefix_(packed_info, t_starts, t_ends, sigmas, rgbs, rgb, opacity,
         rc = _lib.lib().ced_composite_prefix(packed_info.shape[0], _p(packed_info), _p(t_starts), _p(t_ends),
                                              _p(sigmas), _p(rgbs), _p(rgb), _p(opacity), _p(depth), _stream())
     _lib.check(rc, "composite_prefix")
+
+
+def composite_step_(packed_info, t_starts, t_ends, sigmas, rgbs, rgb, opacity, depth, opc_thres, n_samples_iter,
+                    ray_mask, stats):
+    """composite_prefix_ + mask / alive-count / sample-count bookkeeping (cednerf/utils.py:301-307)."""
+    _chk(packed_info, torch.int64, "packed_info"); _chk(stats, torch.int64, "stats")
+    for nm, t in (("rgb", rgb), ("opacity", opacity), ("depth", depth)):
+        _chk(t, torch.float32, nm)
+    assert ray_mask.dtype == torch.bool and ray_mask.is_cuda and ray_mask.shape[0] == packed_info.shape[0]
+    with profiling.span("composite", 0):
+        rc = _lib.lib().ced_composite_step(packed_info.shape[0], _p(packed_info), _p(t_starts), _p(t_ends),
+                                           _p(sigmas), _p(rgbs), _p(rgb), _p(opacity), _p(depth), float(opc_thres),
+                                           int(n_samples_iter), _p(ray_mask), _p(stats), _stream())
+    _lib.check(rc, "composite_step")
 
 
 def composite_test_(sigmas, rgbs, t_start, t_end, pack_info, alive_indices, T_threshold, alpha_threshold, opacity,

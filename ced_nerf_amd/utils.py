@@ -135,23 +135,42 @@ def render_image_test(
     t_sorted, t_indices = sort_intersections(t_mins, t_maxs)
     opc_thres = 1 - early_stop_eps
     op_flat, dp_flat = opacity.view(-1), depth.view(-1)
-
+    binaries = estimator.binaries
+    # Per-iteration bookkeeping stays on the device: the composite kernel updates the ray mask and
+    # counts the surviving rays / composited samples; the host reads both with one 16-byte copy
+    # (the single sync per iteration that the reference's `ray_mask.sum().item()` also pays).
+    stats = torch.zeros((max(int(max_samples), 1) + 1, 2), device=device, dtype=torch.int64)
+    host_stats = torch.zeros((2,), dtype=torch.int64).pin_memory()
+    stream = torch.cuda.current_stream()
+    N_alive = N_rays
+    it = 0
     while iter_samples < max_samples:
-        N_alive = ray_mask.sum().item()
         if N_alive == 0:
             break
         N_samples = max(min(N_rays // N_alive, 64), min_samples)
         iter_samples += N_samples
-        t_starts, t_ends, ray_indices, packed_info, termination_planes = march_packed(
-            rays_o, rays_d, estimator.binaries, aabbs, near_planes, far_planes, render_step_size, cone_angle,
-            N_samples, ray_mask, t_sorted, t_indices, hits)
-        if ray_indices.shape[0] > 0:
-            rgbs, sigmas = radiance_field.query_rays(rays_o, rays_d, ray_indices, t_starts, t_ends, timestamps,
-                                                     want_rgb=True)
-            ops.composite_prefix_(packed_info, t_starts, t_ends, sigmas, rgbs, rgb, op_flat, dp_flat)
-        near_planes = termination_planes
-        ray_mask = torch.logical_and(op_flat <= opc_thres, packed_info[:, 1] == N_samples)
-        total_samples += ray_indices.shape[0]
+        bound = N_alive * N_samples                       # host-known upper bound of this iteration's samples
+        counts = torch.empty((N_rays,), device=device, dtype=torch.int64)
+        march = (rays_o, rays_d, binaries, aabbs, near_planes, far_planes, render_step_size, cone_angle, N_samples,
+                 ray_mask, t_sorted, t_indices, hits)
+        ops.traverse_grids_raw(*march, 0, counts=counts)
+        incl = torch.cumsum(counts, 0)
+        t_starts = torch.empty((bound,), device=device, dtype=torch.float32)
+        t_ends = torch.empty((bound,), device=device, dtype=torch.float32)
+        ray_indices = torch.empty((bound,), device=device, dtype=torch.int64)
+        packed_info = torch.empty((N_rays, 2), device=device, dtype=torch.int64)
+        # fill; the termination planes overwrite the near planes in place (cednerf/utils.py:301)
+        ops.traverse_grids_raw(*march, 3, base=incl, counts=counts, t_starts=t_starts, t_ends=t_ends,
+                               ray_indices=ray_indices, termination_planes=near_planes, packed_info_out=packed_info)
+        rgbs, sigmas = radiance_field.query_rays(rays_o, rays_d, ray_indices, t_starts, t_ends, timestamps,
+                                                 want_rgb=True, n_dev=incl[-1:])
+        ops.composite_step_(packed_info, t_starts, t_ends, sigmas, rgbs, rgb, op_flat, dp_flat, opc_thres, N_samples,
+                            ray_mask, stats[it])
+        host_stats.copy_(stats[it], non_blocking=True)
+        stream.synchronize()
+        N_alive = int(host_stats[0])
+        total_samples += int(host_stats[1])
+        it += 1
 
     bk = None if render_bkgd is None else render_bkgd.to(device, torch.float32).reshape(-1).contiguous()
     ops.finalize_pixels_(bk, rgb, op_flat, dp_flat)

@@ -98,7 +98,11 @@ int ced_ray_aabb_intersect(int64_t n_rays, const float *rays_o, const float *ray
  *   mode 0  count: writes counts[n_rays] and termination_planes (t_starts/t_ends/ray_indices unused);
  *   mode 1  fill : writes samples of ray r at base[r] + i (base = exclusive scan of counts);
  *   mode 2  over-allocate (nerfacc `over_allocate=True`): ray r owns slots [r*limit, (r+1)*limit),
- *           counts[r] tells how many are valid; `base` unused; requires limit > 0.
+ *           counts[r] tells how many are valid; `base` unused; requires limit > 0;
+ *   mode 3  fill, with `base` = INCLUSIVE scan of the counts of a preceding mode-0 call and
+ *           `counts` still holding those counts (start of ray r = base[r] - counts[r]).
+ * packed_info_out (may be NULL): [n_rays,2] = (start, count) written by the same launch.
+ * near_planes and termination_planes may alias (each ray reads its near plane before writing).
  * rays_mask may be NULL (all rays).  ray_indices may be NULL.  binaries: [n_grids,res,res,res]
  * bytes; t_sorted/t_indices: [n_rays, 2*n_grids]; hits: [n_rays, n_grids]. */
 int ced_traverse_grids(int64_t n_rays, const float *rays_o, const float *rays_d,
@@ -108,7 +112,7 @@ int ced_traverse_grids(int64_t n_rays, const float *rays_o, const float *rays_d,
                        const float *t_sorted, const int64_t *t_indices, const uint8_t *hits,
                        int32_t mode, const int64_t *base,
                        int64_t *counts, float *t_starts, float *t_ends, int64_t *ray_indices,
-                       float *termination_planes, void *stream);
+                       float *termination_planes, int64_t *packed_info_out, void *stream);
 
 /* hash_encoder(x): the tcnn HashGrid forward at cednerf/model.py:384 (spec
  * hash_encoder_half.py:112-161).  x [n,3] in [0,1] (clamped), t [n] or NULL (temporal only),
@@ -125,8 +129,11 @@ int ced_field_forward(const ced_field_desc *desc, int64_t n, const float *positi
 
 /* The sigma_fn / rgb_sigma_fn closures of the render drivers (cednerf/utils.py:74-104,181-195)
  * fused with the field: positions = o[ray] + d[ray]*(t0+t1)/2, t = timestamps[t_per_ray ? ray : 0].
- * want_rgb == 0 evaluates the density only (sigma_fn). */
-int ced_field_forward_rays(const ced_field_desc *desc, int64_t n, const float *rays_o, const float *rays_d,
+ * want_rgb == 0 evaluates the density only (sigma_fn).
+ * n_dev (may be NULL): device scalar; the kernel evaluates min(n, *n_dev) samples, so a caller
+ * that only knows an upper bound of the sample count on the host needs no device->host sync. */
+int ced_field_forward_rays(const ced_field_desc *desc, int64_t n, const int64_t *n_dev,
+                           const float *rays_o, const float *rays_d,
                            const int64_t *ray_indices, const float *t_starts, const float *t_ends,
                            const float *timestamps, int32_t t_per_ray, int32_t want_rgb,
                            float *rgb, float *sigma, void *stream);
@@ -155,6 +162,16 @@ int ced_visibility_mask(int64_t n_rays, const int64_t *packed_info, const float 
 int ced_composite_prefix(int64_t n_rays, const int64_t *packed_info, const float *t_starts,
                          const float *t_ends, const float *sigmas, const float *rgbs,
                          float *rgb, float *opacity, float *depth, void *stream);
+
+/* ced_composite_prefix plus the per-iteration bookkeeping of cednerf/utils.py:301-307 in the same
+ * launch: ray_mask[r] = opacity[r] <= opc_thres && count[r] == n_samples_iter, and
+ * stats[0] += number of rays still alive, stats[1] += samples composited (device int64[2], the
+ * caller zeroes it).  Lets the host loop read both numbers with a single 16-byte copy. */
+int ced_composite_step(int64_t n_rays, const int64_t *packed_info, const float *t_starts,
+                       const float *t_ends, const float *sigmas, const float *rgbs,
+                       float *rgb, float *opacity, float *depth,
+                       float opc_thres, int32_t n_samples_iter, uint8_t *ray_mask, int64_t *stats,
+                       void *stream);
 
 /* composite_test -- cednerf/taichi_kernel/volume_render_test.py:4-59 (same arguments, same
  * in-place semantics; alive_indices entries are set to -1 when a ray finishes). */

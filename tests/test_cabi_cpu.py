@@ -34,7 +34,7 @@ def test_argument_errors_are_reported_not_thrown():
     assert rc == -1 and b"null pointer" in L.ced_last_error_string()
     assert L.ced_ray_aabb_intersect(0, None, None, 1, None, 0.0, 1.0, 1.0, None, None, None, None) == 0   # empty input
     rc = L.ced_traverse_grids(4, None, None, None, 1, 128, None, None, None, 1e-3, 0.0, 0, None, None, None, None, 7,
-                              None, None, None, None, None, None, None)
+                              None, None, None, None, None, None, None, None)
     assert rc == -1 and b"mode" in L.ced_last_error_string()
     assert L.ced_accumulate_along_rays(3, None, None, None, 3, None, None) == -1
     with pytest.raises(RuntimeError, match="accumulate_along_rays"):
