@@ -94,19 +94,27 @@ def main():
     origins = torch.stack([T(f["origins"]) for f in frames])        # [F,H,W,3]
     viewdirs = torch.stack([T(f["viewdirs"]) for f in frames])
     ts = T(sc["timestamps"])
+    from ced_nerf_amd import ops
     renderer = cdist.ShardedRenderer(field, est, world, rank, dev, max_samples=args.max_samples, render_kwargs=rk)
     renderer.set_rays(origins, viewdirs)
+    tracer = ops.FrameTracer(capacity=128, with_events=True)     # HIP events around every field launch
+    renderer.tracer = tracer
+    field_ms, field_launches, field_samples = [0.0], [0], [0]
 
     def step():
-        return renderer.render(ts)
+        out = renderer.render(ts)
+        # the frame call returns after its last per-iteration sync, so these events have completed
+        ms = tracer.field_ms()
+        field_ms[0] += sum(ms); field_launches[0] += len(ms)
+        field_samples[0] += sum(it["n_new"] for it in tracer.iterations())
+        return out
 
     for _ in range(args.warmup):
         step()
-    from ced_nerf_amd import profiling
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
-    profiling.start()
+    field_ms[0], field_launches[0], field_samples[0] = 0.0, 0, 0
     t0 = time.perf_counter()
     samples_local = 0
     for _ in range(args.steps):
@@ -116,7 +124,7 @@ def main():
     if world > 1:
         dist.barrier()
     dt = time.perf_counter() - t0
-    prof = profiling.stop()
+    prof = {"field": {"ms": field_ms[0], "launches": field_launches[0], "units": float(field_samples[0])}}
     tt = torch.tensor([dt, float(samples_local)], device=dev, dtype=torch.float64)
     if world > 1:
         tmax = tt.clone(); dist.all_reduce(tmax, op=dist.ReduceOp.MAX)

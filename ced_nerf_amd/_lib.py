@@ -13,7 +13,7 @@ from typing import List, Optional
 _PKG = os.path.dirname(os.path.abspath(__file__))
 _ROOT = os.path.dirname(_PKG)
 LIB_PATH = os.path.join(_PKG, "libcednerf_hip.so")
-SOURCES = ["runtime.hip", "march.hip", "composite.hip", "field.hip"]
+SOURCES = ["runtime.hip", "march.hip", "composite.hip", "field.hip", "frame.hip"]
 HIPCC_FLAGS = ["--offload-arch=gfx950", "-O3", "-ffp-contract=off", "-fPIC", "-shared", "-std=c++17"]
 MAX_LEVELS = 16
 
@@ -38,6 +38,16 @@ class FieldDesc(C.Structure):
     ]
 
 
+class FrameTrace(C.Structure):
+    """ced_frame_trace"""
+    _fields_ = [
+        ("capacity", C.c_int32), ("n_iters", C.c_int32),
+        ("field_begin", C.POINTER(C.c_void_p)), ("field_end", C.POINTER(C.c_void_p)),
+        ("iter_alive", C.POINTER(C.c_int64)), ("iter_n_samples", C.POINTER(C.c_int64)),
+        ("iter_samples", C.POINTER(C.c_int64)),
+    ]
+
+
 _vp, _i64, _i32, _f = C.c_void_p, C.c_int64, C.c_int32, C.c_float
 
 # name -> (restype, argtypes); one entry per function declared in include/cednerf_hip.h
@@ -49,6 +59,7 @@ PROTOTYPES = {
     "ced_ray_aabb_intersect": (C.c_int, [_i64, _vp, _vp, _i32, _vp, _f, _f, _f, _vp, _vp, _vp, _vp]),
     "ced_traverse_grids": (C.c_int, [_i64, _vp, _vp, _vp, _i32, _i32, _vp, _vp, _vp, _f, _f, _i32, _vp, _vp, _vp, _vp,
                                      _i32, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "ced_host_skip_march": (_f, [_f, _f, _f, _f]),
     "ced_hash_encode": (C.c_int, [C.POINTER(HashDesc), _i64, _vp, _vp, _vp, _vp]),
     "ced_field_forward": (C.c_int, [C.POINTER(FieldDesc), _i64, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "ced_field_forward_rays": (C.c_int, [C.POINTER(FieldDesc), _i64, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i32, _i32,
@@ -60,6 +71,10 @@ PROTOTYPES = {
     "ced_composite_step": (C.c_int, [_i64, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _f, _i32, _vp, _vp, _vp]),
     "ced_composite_test": (C.c_int, [_i64, _vp, _vp, _vp, _vp, _vp, _vp, _f, _f, _vp, _vp, _vp, _vp]),
     "ced_finalize_pixels": (C.c_int, [_i64, _vp, _vp, _vp, _vp, _vp]),
+    "ced_render_image_test_workspace_bytes": (_i64, [_i64, _i32, _f, _i32]),
+    "ced_render_image_test": (C.c_int, [C.POINTER(FieldDesc), _i64, _vp, _vp, _vp, _i32, _i32, _vp, _f, _f, _f, _f, _f,
+                                        _i32, _vp, _i32, _vp, _vp, _vp, _vp, _vp, _i64, _vp, C.POINTER(_i64),
+                                        C.POINTER(FrameTrace), _vp]),
 }
 
 
@@ -67,7 +82,7 @@ def build(force: bool = False, verbose: bool = False) -> str:
     """Compile every HIP source for gfx950 into the in-tree shared library (hipcc cross-compiles
     without a GPU)."""
     srcs = [os.path.join(_PKG, "csrc", s) for s in SOURCES]
-    deps = srcs + [os.path.join(_PKG, "csrc", "ced_common.hpp"), os.path.join(_ROOT, "include", "cednerf_hip.h")]
+    deps = srcs + [os.path.join(_PKG, "csrc", h) for h in ("ced_common.hpp", "march_core.hpp", "field_args.hpp")] + [ os.path.join(_ROOT, "include", "cednerf_hip.h")]
     if not force and os.path.exists(LIB_PATH) and all(os.path.getmtime(LIB_PATH) >= os.path.getmtime(d) for d in deps):
         return LIB_PATH
     hipcc = os.environ.get("HIPCC", "hipcc")

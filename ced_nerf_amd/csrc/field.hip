@@ -17,6 +17,7 @@
 // {2g, 2g+1, 8+2g, 9+2g} of its 16 samples, so the gathered features land in B-operand order
 // after two such transposes and the 128 gathers per sample are spread over 4 lanes.
 #include "ced_common.hpp"
+#include "field_args.hpp"
 
 namespace ced {
 
@@ -46,24 +47,6 @@ template <bool TE> struct Blob {
 };
 constexpr int kMaxBlobFloats = Blob<true>::TOTAL;
 
-struct FieldArgs {
-    int64_t n;
-    const int64_t *n_dev;                             // optional device-side sample count (<= n)
-    const float *pos, *t, *dir;                       // explicit mode
-    const float *rays_o, *rays_d;                     // rays mode
-    const int64_t *ray_idx;
-    const float *t0, *t1, *timestamps;
-    int rays_mode, t_per_ray, want_rgb;
-    float *rgb, *sigma, *geo;
-    float aabb[6];
-    float moving_step;
-    int use_div, time_mode;
-    const float *weights;
-    int table_dtype, temporal;
-    const void *table;
-    float scale[CED_MAX_LEVELS];
-    uint32_t res[CED_MAX_LEVELS], offset[CED_MAX_LEVELS], size[CED_MAX_LEVELS], hashed[CED_MAX_LEVELS];
-};
 
 // ---- 4x4 transpose between the wave's four 16-lane groups and four registers ------------------
 // out reg s on lane group q  =  in reg q on lane group s
@@ -306,7 +289,7 @@ __global__ __launch_bounds__(FIELD_THREADS, 2) void field_kernel(FieldArgs A)
             s = s < n_eff ? s : n_eff - 1;
             sidx[j] = s;
             if (A.rays_mode) {
-                const int64_t r = A.ray_idx[s];
+                const int64_t r = A.ray_idx32 ? (int64_t)A.ray_idx32[s] : A.ray_idx[s];
                 ridx[j] = r;
                 const float tm2 = A.t0[s] + A.t1[s];
 #pragma unroll
@@ -519,7 +502,7 @@ static int validate_hash(const ced_hash_desc *h, const char *who)
     return CED_OK;
 }
 
-static int launch_field(const ced_field_desc *d, FieldArgs &A, void *stream)
+int launch_field(const ced_field_desc *d, FieldArgs &A, void *stream)
 {
     int rc = validate_hash(&d->hash, "field_forward");
     if (rc) return rc;

@@ -1,0 +1,32 @@
+// Kernel-argument block of the fused field kernel (field.hip), shared with the frame renderer.
+#pragma once
+#include <cstdint>
+
+#include "../../include/cednerf_hip.h"
+
+namespace ced {
+
+struct FieldArgs {
+    int64_t n;
+    const int64_t *n_dev;                             // optional device-side sample count (<= n)
+    const float *pos, *t, *dir;                       // explicit mode
+    const float *rays_o, *rays_d;                     // rays mode
+    const int64_t *ray_idx;
+    const int32_t *ray_idx32;                         // alternative 32-bit ray indices (frame renderer)
+    const float *t0, *t1, *timestamps;
+    int rays_mode, t_per_ray, want_rgb;
+    float *rgb, *sigma, *geo;
+    float aabb[6];
+    float moving_step;
+    int use_div, time_mode;
+    const float *weights;
+    int table_dtype, temporal;
+    const void *table;
+    float scale[CED_MAX_LEVELS];
+    uint32_t res[CED_MAX_LEVELS], offset[CED_MAX_LEVELS], size[CED_MAX_LEVELS], hashed[CED_MAX_LEVELS];
+};
+
+// Fills the field/hash parts of A from the descriptor, validates, and launches on `stream`.
+int launch_field(const ced_field_desc *d, FieldArgs &A, void *stream);
+
+}  // namespace ced

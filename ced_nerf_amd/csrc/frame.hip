@@ -1,0 +1,347 @@
+// Frame renderer: the whole of render_image_test (cednerf/utils.py:153-318) behind one C call.
+//
+// Same algorithm and the same per-ray sample sets as the reference's host loop (image-global
+// schedule N_samples = clamp(N_rays // N_alive, min, 64), termination checked between iterations),
+// but an iteration is three launches instead of ~15 kernels + torch glue:
+//   march_alloc : one wave per 64 rays marches its alive rays ONCE, stages the (t_start, t_end)
+//                 pairs in LDS, reserves a contiguous output range with a wave prefix sum + one
+//                 atomic per wave, and writes the ray-packed samples (no count pass, no scan);
+//   field       : the fused field kernel of field.hip on those samples (count read from device memory);
+//   composite   : per-ray front-to-back compositing + ray-mask update + alive/sample counters.
+// The host reads (n_alive, n_samples) with one 16-byte copy per iteration -- the same single sync the
+// reference pays at cednerf/utils.py:231.  Sample order in memory differs from nerfacc's (waves
+// reserve ranges in arrival order) but every ray's samples are contiguous and in order, so pixels,
+// sample counts and the schedule are bit-identical.
+#include <cfloat>
+
+#include "ced_common.hpp"
+#include "field_args.hpp"
+#include "march_core.hpp"
+
+namespace ced {
+
+__device__ __forceinline__ bool slab_test(const float o[3], const float inv_d[3], const float *__restrict__ aabb,
+                                          float &tmin_out, float &tmax_out)
+{
+    // nerfacc.ray_aabb_intersect with near = -inf, far = +inf (cednerf/utils.py:215)
+    float tmin, tmax, tymin, tymax, tzmin, tzmax;
+    if (inv_d[0] >= 0) { tmin = (aabb[0] - o[0]) * inv_d[0]; tmax = (aabb[3] - o[0]) * inv_d[0]; }
+    else               { tmin = (aabb[3] - o[0]) * inv_d[0]; tmax = (aabb[0] - o[0]) * inv_d[0]; }
+    if (inv_d[1] >= 0) { tymin = (aabb[1] - o[1]) * inv_d[1]; tymax = (aabb[4] - o[1]) * inv_d[1]; }
+    else               { tymin = (aabb[4] - o[1]) * inv_d[1]; tymax = (aabb[1] - o[1]) * inv_d[1]; }
+    if (tmin > tymax || tymin > tmax) return false;
+    if (tymin > tmin) tmin = tymin;
+    if (tymax < tmax) tmax = tymax;
+    if (inv_d[2] >= 0) { tzmin = (aabb[2] - o[2]) * inv_d[2]; tzmax = (aabb[5] - o[2]) * inv_d[2]; }
+    else               { tzmin = (aabb[5] - o[2]) * inv_d[2]; tzmax = (aabb[2] - o[2]) * inv_d[2]; }
+    if (tmin > tzmax || tzmin > tmax) return false;
+    if (tzmin > tmin) tmin = tzmin;
+    if (tzmax < tmax) tmax = tzmax;
+    if (tmax <= 0) return false;
+    tmin_out = tmin;
+    tmax_out = tmax;
+    return true;
+}
+
+constexpr int kMaxGrids = 8;
+
+// Per-ray setup of cednerf/utils.py:197-225: zero the pixel accumulators, all rays alive, near
+// planes, ray/AABB intersection per grid level and the stably sorted entry/exit event list.
+__global__ __launch_bounds__(256) void frame_prep_kernel(int64_t n_rays, const float *__restrict__ rays_o,
+                                                         const float *__restrict__ rays_d, int m,
+                                                         const float *__restrict__ aabbs, float near_plane,
+                                                         float *__restrict__ t_sorted, int64_t *__restrict__ t_indices,
+                                                         uint8_t *__restrict__ hits, float *__restrict__ near_planes,
+                                                         uint8_t *__restrict__ ray_mask, float *__restrict__ rgb,
+                                                         float *__restrict__ opacity, float *__restrict__ depth)
+{
+    int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= n_rays) return;
+    const float o[3] = { rays_o[3 * r], rays_o[3 * r + 1], rays_o[3 * r + 2] };
+    const float inv_d[3] = { 1.0f / rays_d[3 * r], 1.0f / rays_d[3 * r + 1], 1.0f / rays_d[3 * r + 2] };
+    float ev[2 * kMaxGrids];
+    int id[2 * kMaxGrids];
+    for (int a = 0; a < m; ++a) {
+        float t0 = __builtin_inff(), t1 = __builtin_inff();
+        bool hit = slab_test(o, inv_d, aabbs + 6 * a, t0, t1);
+        if (!hit) { t0 = __builtin_inff(); t1 = __builtin_inff(); }
+        hits[r * m + a] = hit ? 1 : 0;
+        ev[a] = t0; id[a] = a;
+        ev[m + a] = t1; id[m + a] = m + a;
+    }
+    if (m > 1) {            // stable insertion sort of the 2m events (torch.sort(..., stable=True))
+        for (int i = 1; i < 2 * m; ++i) {
+            float v = ev[i];
+            int k = id[i], j = i - 1;
+            while (j >= 0 && ev[j] > v) { ev[j + 1] = ev[j]; id[j + 1] = id[j]; --j; }
+            ev[j + 1] = v; id[j + 1] = k;
+        }
+    }
+    for (int i = 0; i < 2 * m; ++i) {
+        t_sorted[r * 2 * m + i] = ev[i];
+        t_indices[r * 2 * m + i] = id[i];
+    }
+    near_planes[r] = near_plane;
+    ray_mask[r] = 1;
+    rgb[3 * r] = 0.0f; rgb[3 * r + 1] = 0.0f; rgb[3 * r + 2] = 0.0f;
+    opacity[r] = 0.0f;
+    depth[r] = 0.0f;
+}
+
+struct MarchArgs {
+    int64_t n_rays;
+    const float *rays_o, *rays_d;
+    GridSpec grid;
+    float *near_planes;            // in: near plane, out: termination plane (cednerf/utils.py:301)
+    float far_plane;
+    const uint8_t *ray_mask;
+    const float *t_sorted;
+    const int64_t *t_indices;
+    const uint8_t *hits;
+    float *t_starts, *t_ends;
+    int32_t *ray_idx;
+    int32_t *packed;               // [n_rays, 2] (start, count)
+    unsigned long long *counter;   // samples reserved so far in this iteration
+};
+
+// One wave (64 rays) per workgroup; dynamic LDS = 64 * limit * 8 bytes, slot-major so a wave's
+// stores of slot i are 512 contiguous bytes (conflict-free).
+__global__ __launch_bounds__(64) void march_alloc_kernel(MarchArgs A)
+{
+    extern __shared__ __attribute__((aligned(16))) float2 stage[];
+    const int lane = threadIdx.x;
+    const int64_t r = (int64_t)blockIdx.x * 64 + lane;
+    int n = 0;
+    if (r < A.n_rays && A.ray_mask[r]) {
+        const float o[3] = { A.rays_o[3 * r], A.rays_o[3 * r + 1], A.rays_o[3 * r + 2] };
+        const float d[3] = { A.rays_d[3 * r], A.rays_d[3 * r + 1], A.rays_d[3 * r + 2] };
+        const int m = A.grid.n_grids;
+        float t_term;
+        n = traverse_ray(
+            A.grid, o, d, A.near_planes[r], A.far_plane, A.t_sorted + r * 2 * m, A.t_indices + r * 2 * m,
+            A.hits + r * m, [&](int i, float t0, float t1) { stage[i * 64 + lane] = make_float2(t0, t1); }, t_term);
+        A.near_planes[r] = t_term;
+    }
+    // wave-inclusive prefix sum of the counts, one atomic for the whole wave
+    int incl = n;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+        int v = __shfl_up(incl, off, 64);
+        if (lane >= off) incl += v;
+    }
+    const int total = __shfl(incl, 63, 64);
+    unsigned long long wave_base = 0;
+    if (lane == 0 && total > 0) wave_base = atomicAdd(A.counter, (unsigned long long)total);
+    wave_base = __shfl(wave_base, 0, 64);
+    const int64_t start = (int64_t)wave_base + (incl - n);
+    if (r < A.n_rays) {
+        A.packed[2 * r] = (int32_t)start;
+        A.packed[2 * r + 1] = n;
+    }
+    for (int i = 0; i < n; ++i) {
+        const float2 v = stage[i * 64 + lane];
+        A.t_starts[start + i] = v.x;
+        A.t_ends[start + i] = v.y;
+        A.ray_idx[start + i] = (int32_t)r;
+    }
+}
+
+// composite_prefix (cednerf/utils.py:274-299) + ray bookkeeping (utils.py:301-307), 32-bit packed_info
+__global__ __launch_bounds__(256) void frame_composite_kernel(int64_t n_rays, const int32_t *__restrict__ packed,
+                                                              const float *__restrict__ t0,
+                                                              const float *__restrict__ t1,
+                                                              const float *__restrict__ sig,
+                                                              const float *__restrict__ rgbs, float *__restrict__ rgb,
+                                                              float *__restrict__ opacity, float *__restrict__ depth,
+                                                              float opc_thres, int n_samples_iter,
+                                                              uint8_t *__restrict__ ray_mask,
+                                                              unsigned long long *__restrict__ stats)
+{
+    int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    int cnt = 0;
+    bool alive = false;
+    if (r < n_rays && ray_mask[r]) {
+        const int s0 = packed[2 * r];
+        cnt = packed[2 * r + 1];
+        float op = opacity[r];
+        if (cnt > 0) {
+            const float prefix = 1.0f - op;
+            float c0 = rgb[3 * r], c1 = rgb[3 * r + 1], c2 = rgb[3 * r + 2], dp = depth[r];
+            float acc = 0.0f;
+            for (int i = s0; i < s0 + cnt; ++i) {
+                float ts = t0[i], te = t1[i];
+                float sd = sig[i] * (te - ts);
+                float a = 1.0f - det_expf(-sd);
+                float t = det_expf(-acc) * prefix;
+                float w = t * a;
+                c0 = c0 + w * rgbs[3 * i];
+                c1 = c1 + w * rgbs[3 * i + 1];
+                c2 = c2 + w * rgbs[3 * i + 2];
+                op = op + w;
+                dp = dp + w * ((ts + te) / 2.0f);
+                acc = acc + sd;
+            }
+            rgb[3 * r] = c0; rgb[3 * r + 1] = c1; rgb[3 * r + 2] = c2;
+            opacity[r] = op;
+            depth[r] = dp;
+        }
+        alive = (op <= opc_thres) && (cnt == n_samples_iter);
+        ray_mask[r] = alive ? 1 : 0;
+    }
+    const unsigned long long ballot = __ballot(alive);
+    int c = cnt;
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) c += __shfl_down(c, off, 64);
+    if ((threadIdx.x & 63) == 0) {
+        const int n_alive = __builtin_popcountll(ballot);
+        if (n_alive) atomicAdd(&stats[0], (unsigned long long)n_alive);
+        if (c) atomicAdd(&stats[1], (unsigned long long)c);
+    }
+}
+
+__global__ __launch_bounds__(256) void frame_finalize_kernel(int64_t n_rays, const float *__restrict__ bkgd,
+                                                             float *__restrict__ rgb, const float *__restrict__ opacity,
+                                                             float *__restrict__ depth)
+{
+    int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= n_rays) return;
+    float op = opacity[r];
+    if (bkgd) {
+        float rem = 1.0f - op;
+        rgb[3 * r] = rgb[3 * r] + bkgd[0] * rem;
+        rgb[3 * r + 1] = rgb[3 * r + 1] + bkgd[1] * rem;
+        rgb[3 * r + 2] = rgb[3 * r + 2] + bkgd[2] * rem;
+    }
+    depth[r] = depth[r] / __builtin_fmaxf(op, FLT_EPSILON);
+}
+
+static inline size_t align_up(size_t x) { return (x + 255) & ~(size_t)255; }
+
+struct FrameWorkspace {
+    float *t_sorted; int64_t *t_indices; uint8_t *hits; float *near; uint8_t *mask; int32_t *packed;
+    unsigned long long *stats;      // [iters+1][4]: alive, samples, reserved, pad
+    float *t0, *t1; int32_t *ridx; float *sigma, *rgbs;
+    size_t bytes;
+};
+
+static FrameWorkspace carve(void *base, int64_t n, int m, int64_t cap, int max_iters)
+{
+    FrameWorkspace w{};
+    size_t off = 0;
+    auto take = [&](size_t bytes) { size_t o = off; off = align_up(off + bytes); return (char *)base + o; };
+    w.t_sorted = (float *)take((size_t)n * 2 * m * 4);
+    w.t_indices = (int64_t *)take((size_t)n * 2 * m * 8);
+    w.hits = (uint8_t *)take((size_t)n * m);
+    w.near = (float *)take((size_t)n * 4);
+    w.mask = (uint8_t *)take((size_t)n);
+    w.packed = (int32_t *)take((size_t)n * 8);
+    w.stats = (unsigned long long *)take((size_t)(max_iters + 1) * 32);
+    w.t0 = (float *)take((size_t)cap * 4);
+    w.t1 = (float *)take((size_t)cap * 4);
+    w.ridx = (int32_t *)take((size_t)cap * 4);
+    w.sigma = (float *)take((size_t)cap * 4);
+    w.rgbs = (float *)take((size_t)cap * 12);
+    w.bytes = off;
+    return w;
+}
+
+static inline int min_samples_of(float cone_angle) { return cone_angle == 0.0f ? 1 : 4; }
+
+}  // namespace ced
+
+extern "C" int64_t ced_render_image_test_workspace_bytes(int64_t n_rays, int32_t n_grids, float cone_angle,
+                                                         int32_t max_samples)
+{
+    if (n_rays < 0 || n_grids < 1 || n_grids > ced::kMaxGrids || max_samples < 0) return -1;
+    const int64_t cap = n_rays * ced::min_samples_of(cone_angle);
+    return (int64_t)ced::carve(nullptr, n_rays, n_grids, cap, max_samples + 1).bytes;
+}
+
+extern "C" int ced_render_image_test(const ced_field_desc *field, int64_t n_rays, const float *rays_o,
+                                     const float *rays_d, const uint8_t *binaries, int32_t n_grids, int32_t res,
+                                     const float *aabbs, float near_plane, float far_plane, float step_size,
+                                     float cone_angle, float early_stop_eps, int32_t max_samples,
+                                     const float *timestamps, int32_t t_per_ray, const float *bkgd, float *rgb,
+                                     float *opacity, float *depth, void *workspace, int64_t workspace_bytes,
+                                     int64_t *host_stats, int64_t *total_samples_out, ced_frame_trace *trace,
+                                     void *stream_)
+{
+    using namespace ced;
+    hipStream_t stream = (hipStream_t)stream_;
+    CED_REQUIRE(field != nullptr, "render_image_test: null field descriptor");
+    CED_REQUIRE(n_rays >= 0 && n_grids >= 1 && n_grids <= kMaxGrids && res >= 1, "render_image_test: bad sizes");
+    CED_REQUIRE(n_rays < (1ll << 31) / 4, "render_image_test: too many rays for 32-bit sample indices");
+    CED_REQUIRE(max_samples >= 0, "render_image_test: max_samples < 0");
+    if (total_samples_out) *total_samples_out = 0;
+    if (trace) trace->n_iters = 0;
+    if (n_rays == 0) return CED_OK;
+    CED_REQUIRE(rays_o && rays_d && binaries && aabbs && timestamps && rgb && opacity && depth && workspace &&
+                    host_stats,
+                "render_image_test: null pointer");
+    const int min_samples = min_samples_of(cone_angle);
+    const int64_t cap = n_rays * min_samples;
+    FrameWorkspace W = carve(workspace, n_rays, n_grids, cap, max_samples + 1);
+    CED_REQUIRE((int64_t)W.bytes <= workspace_bytes, "render_image_test: workspace too small (%lld < %lld bytes)",
+                (long long)workspace_bytes, (long long)W.bytes);
+    const dim3 blk(256), grd((unsigned)((n_rays + 255) / 256));
+
+    hipLaunchKernelGGL(frame_prep_kernel, grd, blk, 0, stream, n_rays, rays_o, rays_d, (int)n_grids, aabbs, near_plane,
+                       W.t_sorted, W.t_indices, W.hits, W.near, W.mask, rgb, opacity, depth);
+    if (hipMemsetAsync(W.stats, 0, (size_t)(max_samples + 2) * 32, stream) != hipSuccess)
+        return check_launch("render_image_test (memset)");
+    int rc = check_launch("render_image_test (prep)");
+    if (rc) return rc;
+
+    const float opc_thres = (float)(1.0 - (double)early_stop_eps);
+    int64_t n_alive = n_rays, total = 0;
+    int iter_samples = 0, it = 0;
+    while (iter_samples < max_samples && n_alive > 0) {
+        int64_t q = n_rays / n_alive;
+        int n_samples = (int)(q < 64 ? q : 64);
+        if (n_samples < min_samples) n_samples = min_samples;
+        iter_samples += n_samples;
+        unsigned long long *st = W.stats + (size_t)it * 4;
+
+        MarchArgs M{ n_rays, rays_o, rays_d,
+                     GridSpec{ binaries, aabbs, n_grids, res, step_size, cone_angle, n_samples },
+                     W.near, far_plane, W.mask, W.t_sorted, W.t_indices, W.hits, W.t0, W.t1, W.ridx, W.packed, st + 2 };
+        hipLaunchKernelGGL(march_alloc_kernel, dim3((unsigned)((n_rays + 63) / 64)), dim3(64),
+                           (size_t)64 * n_samples * sizeof(float2), stream, M);
+        rc = check_launch("render_image_test (march)");
+        if (rc) return rc;
+
+        FieldArgs F{};
+        F.n = n_alive * n_samples;          // host-side upper bound; the kernel reads the exact count
+        F.n_dev = reinterpret_cast<const int64_t *>(st + 2);
+        F.rays_o = rays_o; F.rays_d = rays_d; F.ray_idx32 = W.ridx;
+        F.t0 = W.t0; F.t1 = W.t1; F.timestamps = timestamps;
+        F.rays_mode = 1; F.t_per_ray = t_per_ray ? 1 : 0; F.want_rgb = 1;
+        F.rgb = W.rgbs; F.sigma = W.sigma; F.geo = nullptr;
+        if (trace && it < trace->capacity && trace->field_begin) hipEventRecord((hipEvent_t)trace->field_begin[it], stream);
+        rc = launch_field(field, F, stream_);
+        if (rc) return rc;
+        if (trace && it < trace->capacity && trace->field_end) hipEventRecord((hipEvent_t)trace->field_end[it], stream);
+
+        hipLaunchKernelGGL(frame_composite_kernel, grd, blk, 0, stream, n_rays, W.packed, W.t0, W.t1, W.sigma, W.rgbs, rgb,
+                           opacity, depth, opc_thres, n_samples, W.mask, st);
+        rc = check_launch("render_image_test (composite)");
+        if (rc) return rc;
+        if (hipMemcpyAsync(host_stats, st, 16, hipMemcpyDeviceToHost, stream) != hipSuccess ||
+            hipStreamSynchronize(stream) != hipSuccess)
+            return check_launch("render_image_test (stats copy)");
+        if (trace && it < trace->capacity) {
+            if (trace->iter_alive) trace->iter_alive[it] = n_alive;
+            if (trace->iter_n_samples) trace->iter_n_samples[it] = n_samples;
+            if (trace->iter_samples) trace->iter_samples[it] = host_stats[1];
+        }
+        n_alive = host_stats[0];
+        total += host_stats[1];
+        ++it;
+    }
+    if (trace) trace->n_iters = it;
+    hipLaunchKernelGGL(frame_finalize_kernel, grd, blk, 0, stream, n_rays, bkgd, rgb, opacity, depth);
+    rc = check_launch("render_image_test (finalize)");
+    if (rc) return rc;
+    if (total_samples_out) *total_samples_out = total;
+    return CED_OK;
+}

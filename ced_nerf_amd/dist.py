@@ -46,11 +46,12 @@ class ShardedRenderer:
         self.render_kwargs = dict(render_kwargs or {})
         self.render_fn = render_fn or self._hip_render
         self.shape = None
+        self.tracer = None             # optional ops.FrameTracer handed to the native frame call
 
     def _hip_render(self, rays_o, rays_d, timestamps):
         from .utils import Rays, render_image_test
         return render_image_test(self.max_samples, self.field, self.estimator, Rays(rays_o, rays_d),
-                                 timestamps=timestamps, **self.render_kwargs)
+                                 timestamps=timestamps, tracer=self.tracer, **self.render_kwargs)
 
     def set_rays(self, origins: torch.Tensor, viewdirs: torch.Tensor) -> None:
         assert origins.ndim == 4 and origins.shape == viewdirs.shape, "rays must be [F,H,W,3]"

@@ -259,3 +259,81 @@ def finalize_pixels_(bkgd, rgb, opacity, depth):
     _chk(bkgd, torch.float32, "render_bkgd", allow_none=True)
     rc = _lib.lib().ced_finalize_pixels(rgb.shape[0], _p(bkgd), _p(rgb), _p(opacity), _p(depth), _stream())
     _lib.check(rc, "finalize_pixels")
+
+
+# ----------------------------------------------------------------------------------------------
+# frame renderer (the whole render_image_test loop in one native call)
+# ----------------------------------------------------------------------------------------------
+class FrameTracer:
+    """Event pairs + per-iteration counters for ced_render_image_test (see ced_frame_trace)."""
+
+    def __init__(self, capacity: int = 96, with_events: bool = True):
+        self.capacity = capacity
+        self.struct = _lib.FrameTrace()
+        self.struct.capacity = capacity
+        self._alive = (C.c_int64 * capacity)()
+        self._nsamp = (C.c_int64 * capacity)()
+        self._samples = (C.c_int64 * capacity)()
+        self.struct.iter_alive = self._alive
+        self.struct.iter_n_samples = self._nsamp
+        self.struct.iter_samples = self._samples
+        self.events = None
+        if with_events:
+            self.events = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
+                           for _ in range(capacity)]
+            for a, b in self.events:       # torch creates the hipEvent lazily on the first record
+                a.record(); b.record()
+            self._b = (C.c_void_p * capacity)(*[e[0].cuda_event for e in self.events])
+            self._e = (C.c_void_p * capacity)(*[e[1].cuda_event for e in self.events])
+            self.struct.field_begin = self._b
+            self.struct.field_end = self._e
+
+    def iterations(self):
+        n = min(int(self.struct.n_iters), self.capacity)
+        return [dict(n_alive=int(self._alive[i]), n_samples=int(self._nsamp[i]), n_new=int(self._samples[i]))
+                for i in range(n)]
+
+    def field_ms(self):
+        """Per-iteration field-kernel durations (ms); call after the stream has been synchronised."""
+        n = min(int(self.struct.n_iters), self.capacity)
+        return [self.events[i][0].elapsed_time(self.events[i][1]) for i in range(n)]
+
+
+_frame_ws = {}
+
+
+def render_image_test_native(desc: _lib.FieldDesc, rays_o, rays_d, binaries, aabbs, near_plane, far_plane,
+                             render_step_size, cone_angle, early_stop_eps, max_samples, timestamps, t_per_ray, bkgd,
+                             tracer: Optional[FrameTracer] = None):
+    """ced_render_image_test.  Returns (rgb [n,3], opacity [n,1], depth [n,1], total_samples)."""
+    _chk(rays_o, torch.float32, "rays_o"); _chk(rays_d, torch.float32, "rays_d")
+    _chk(aabbs, torch.float32, "aabbs"); _chk(timestamps, torch.float32, "timestamps")
+    _chk(bkgd, torch.float32, "render_bkgd", allow_none=True)
+    assert rays_o.ndim == 2 and rays_o.shape[1] == 3 and rays_o.shape == rays_d.shape
+    assert binaries.is_cuda and binaries.is_contiguous() and binaries.ndim == 4
+    n = rays_o.shape[0]
+    m, res = binaries.shape[0], binaries.shape[1]
+    assert aabbs.shape == (m, 6)
+    if t_per_ray:
+        assert timestamps.numel() == n, "per-ray timestamps must have one entry per ray"
+    dev = rays_o.device
+    L = _lib.lib()
+    need = int(L.ced_render_image_test_workspace_bytes(n, m, float(cone_angle), int(max_samples)))
+    if need < 0:
+        raise ValueError("render_image_test: unsupported sizes")
+    key = (dev.index, torch.cuda.current_stream().cuda_stream)
+    ws = _frame_ws.get(key)
+    if ws is None or ws[0].numel() < need:
+        ws = (torch.empty((max(need, 1),), device=dev, dtype=torch.uint8), torch.zeros((4,), dtype=torch.int64).pin_memory())
+        _frame_ws[key] = ws
+    rgb = torch.empty((n, 3), device=dev, dtype=torch.float32)
+    opacity = torch.empty((n, 1), device=dev, dtype=torch.float32)
+    depth = torch.empty((n, 1), device=dev, dtype=torch.float32)
+    total = C.c_int64(0)
+    rc = L.ced_render_image_test(C.byref(desc), n, _p(rays_o), _p(rays_d), _p(_as_u8(binaries)), m, res, _p(aabbs),
+                                 float(near_plane), float(far_plane), float(render_step_size), float(cone_angle),
+                                 float(early_stop_eps), int(max_samples), _p(timestamps), int(bool(t_per_ray)), _p(bkgd),
+                                 _p(rgb), _p(opacity), _p(depth), _p(ws[0]), ws[0].numel(), C.c_void_p(ws[1].data_ptr()),
+                                 C.byref(total), C.byref(tracer.struct) if tracer is not None else None, _stream())
+    _lib.check(rc, "render_image_test")
+    return rgb, opacity, depth, int(total.value)

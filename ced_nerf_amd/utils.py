@@ -112,10 +112,46 @@ def render_image_test(
     alpha_thre: float = 0.0,
     early_stop_eps: float = 1e-4,
     timestamps: Optional[torch.Tensor] = None,
+    tracer=None,
 ):
     """Iterative eval renderer with per-iteration early termination (cednerf/utils.py:153-318).
     Returns (rgb, opacity, depth, total_samples).  `alpha_thre` is accepted and unused, as in the
-    reference."""
+    reference.  The whole loop runs inside the native library (ced_render_image_test): three
+    launches per iteration; `render_image_test_staged` is the same algorithm driven from Python
+    through the nerfacc-shaped ops."""
+    if timestamps is None:
+        raise NotImplementedError("DNGPradianceField needs timestamps (dnerf path of cednerf/utils.py:186-194)")
+    rays, rays_shape, N_rays = _flatten_rays(rays)
+    rays_o = rays.origins.contiguous().float()
+    rays_d = rays.viewdirs.contiguous().float()
+    bk = None if render_bkgd is None else render_bkgd.to(rays_o.device, torch.float32).reshape(-1).contiguous()
+    ts = timestamps.reshape(-1).float().contiguous()
+    rgb, opacity, depth, total = ops.render_image_test_native(
+        radiance_field._descriptor(), rays_o, rays_d, estimator.binaries, estimator.aabbs.contiguous(), near_plane,
+        far_plane, render_step_size, cone_angle, early_stop_eps, max_samples, ts, bool(radiance_field.training), bk,
+        tracer=tracer)
+    return (rgb.view((*rays_shape[:-1], -1)), opacity.view((*rays_shape[:-1], -1)),
+            depth.view((*rays_shape[:-1], -1)), total)
+
+
+@torch.no_grad()
+def render_image_test_staged(
+    max_samples: int,
+    radiance_field: torch.nn.Module,
+    estimator: OccGridEstimator,
+    rays: Rays,
+    near_plane: float = 0.0,
+    far_plane: float = 1e10,
+    render_step_size: float = 1e-3,
+    render_bkgd: Optional[torch.Tensor] = None,
+    cone_angle: float = 0.0,
+    alpha_thre: float = 0.0,
+    early_stop_eps: float = 1e-4,
+    timestamps: Optional[torch.Tensor] = None,
+):
+    """render_image_test (cednerf/utils.py:153-318) staged from Python through the nerfacc-shaped
+    ops (count -> scan -> fill marching, field, composite_step): the reference's own structure,
+    kept for per-kernel profiling and as a cross-check of the native loop."""
     if timestamps is None:
         raise NotImplementedError("DNGPradianceField needs timestamps (dnerf path of cednerf/utils.py:186-194)")
     rays, rays_shape, N_rays = _flatten_rays(rays)

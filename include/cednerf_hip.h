@@ -114,6 +114,11 @@ int ced_traverse_grids(int64_t n_rays, const float *rays_o, const float *rays_d,
                        int64_t *counts, float *t_starts, float *t_ends, int64_t *ray_indices,
                        float *termination_planes, int64_t *packed_info_out, void *stream);
 
+/* HOST function (validation aid): the kernels' empty-space skip -- advance t_last by whole steps
+ * dt = clamp(t*cone_angle, step_size, 1e10) until t_last + dt/2 >= target -- evaluated on the host
+ * with the same code the device runs (closed form when cone_angle == 0). */
+float ced_host_skip_march(float t_last, float target, float step_size, float cone_angle);
+
 /* hash_encoder(x): the tcnn HashGrid forward at cednerf/model.py:384 (spec
  * hash_encoder_half.py:112-161).  x [n,3] in [0,1] (clamped), t [n] or NULL (temporal only),
  * out [n, 2*n_levels] level-major (hash_encoder_half.py:339-345,385). */
@@ -184,6 +189,48 @@ int ced_composite_test(int64_t n_alive, const float *sigmas, const float *rgbs, 
  * rgb += bkgd * (1 - opacity); depth /= max(opacity, FLT_EPSILON).  bkgd: device [3] or NULL. */
 int ced_finalize_pixels(int64_t n_rays, const float *bkgd, float *rgb, const float *opacity,
                         float *depth, void *stream);
+
+/* Optional per-iteration trace of ced_render_image_test (host struct, host arrays of `capacity`
+ * entries, each may be NULL).  field_begin/field_end are caller-created hipEvent_t handles that the
+ * renderer records on `stream` around the field-kernel launch of iteration i, so a benchmark can
+ * time that kernel live without perturbing the launch sequence. */
+typedef struct ced_frame_trace {
+    int32_t capacity;        /* in  */
+    int32_t n_iters;         /* out: iterations executed */
+    void **field_begin;      /* in  */
+    void **field_end;        /* in  */
+    int64_t *iter_alive;     /* out: rays alive entering iteration i (N_alive, cednerf/utils.py:231) */
+    int64_t *iter_n_samples; /* out: samples per ray requested in iteration i (N_samples, utils.py:235) */
+    int64_t *iter_samples;   /* out: samples marched and composited in iteration i */
+} ced_frame_trace;
+
+/* Device bytes ced_render_image_test needs in `workspace` (negative on bad arguments). */
+int64_t ced_render_image_test_workspace_bytes(int64_t n_rays, int32_t n_grids, float cone_angle,
+                                              int32_t max_samples);
+
+/* render_image_test(max_samples, radiance_field, estimator, rays, near_plane, far_plane,
+ * render_step_size, render_bkgd, cone_angle, alpha_thre, early_stop_eps, timestamps)
+ * -- cednerf/utils.py:153-318, the eval / GUI frame renderer (callers train_real.py:481-493,
+ * :541-553, gui.py:215-228), as ONE call: ray/AABB setup, then per iteration one marching launch,
+ * one fused field launch and one compositing launch, and the background / depth normalisation
+ * at the end.  Same schedule and per-ray sample sets as the reference loop.  `alpha_thre` is not
+ * a parameter because the reference ignores it in this function.
+ *   rays_o, rays_d [n_rays,3]; binaries [n_grids,res,res,res] bytes; aabbs [n_grids,6];
+ *   timestamps: device [1] (t_per_ray = 0, eval) or [n_rays] (t_per_ray = 1); bkgd: device [3] or NULL;
+ *   outputs rgb [n_rays,3], opacity [n_rays], depth [n_rays] (overwritten);
+ *   workspace: device scratch of ced_render_image_test_workspace_bytes() bytes;
+ *   host_stats: PINNED host memory, >= 16 bytes (per-iteration counters land here);
+ *   total_samples_out: host, receives the number of field evaluations (utils.py:307,317).
+ * Unlike the other entry points this one BLOCKS: like the reference loop (utils.py:231) it reads
+ * the alive-ray count back once per iteration. */
+int ced_render_image_test(const ced_field_desc *field, int64_t n_rays, const float *rays_o, const float *rays_d,
+                          const uint8_t *binaries, int32_t n_grids, int32_t res, const float *aabbs,
+                          float near_plane, float far_plane, float render_step_size, float cone_angle,
+                          float early_stop_eps, int32_t max_samples,
+                          const float *timestamps, int32_t t_per_ray, const float *bkgd,
+                          float *rgb, float *opacity, float *depth,
+                          void *workspace, int64_t workspace_bytes, int64_t *host_stats,
+                          int64_t *total_samples_out, ced_frame_trace *trace, void *stream);
 
 #ifdef __cplusplus
 }

@@ -171,6 +171,18 @@ static inline float calc_dt(float t, float cone_angle, float dt_min, float dt_ma
     return fminf(fmaxf(v, dt_min), dt_max);
 }
 
+/* the empty-space skip of traverse_grids on its own (sequential recurrence), for tests */
+float ced_o_skip_march(float t_last, float target, float step_size, float cone_angle)
+{
+    if (step_size <= 0.0f) return target;
+    for (;;) {
+        float dt = calc_dt(t_last, cone_angle, step_size, 1e10f);
+        if (t_last + dt * 0.5f >= target) break;
+        t_last += dt;
+    }
+    return t_last;
+}
+
 static inline int clampi(int v, int lo, int hi) { return v < lo ? lo : (v > hi ? hi : v); }
 
 static int64_t traverse_one_ray(

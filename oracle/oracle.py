@@ -66,6 +66,8 @@ def lib():
         _lib.ced_o_sinf.argtypes = [C.c_float]
         _lib.ced_o_sinpi_phase.restype = C.c_float
         _lib.ced_o_sinpi_phase.argtypes = [C.c_float, C.c_int]
+        _lib.ced_o_skip_march.restype = C.c_float
+        _lib.ced_o_skip_march.argtypes = [C.c_float] * 4
     return _lib
 
 

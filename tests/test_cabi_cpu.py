@@ -43,6 +43,36 @@ def test_argument_errors_are_reported_not_thrown():
     d.hash.n_levels = 12
     assert L.ced_field_forward(C.byref(d), 4, 1, 1, None, None, 1, None, None) != 0
     assert L.ced_field_forward(C.byref(d), 0, None, None, None, None, None, None, None) == 0            # n == 0
+    assert L.ced_render_image_test_workspace_bytes(640000, 1, 0.0, 1024) > 0
+    assert L.ced_render_image_test_workspace_bytes(10, 9, 0.0, 16) < 0                                  # too many grids
+    tot = C.c_int64(-1)
+    assert L.ced_render_image_test(C.byref(d), 0, None, None, None, 1, 128, None, 0.0, 1e10, 5e-3, 0.0, 1e-4, 64, None, 0,
+                                   None, None, None, None, None, 0, None, C.byref(tot), None, None) == 0   # no rays
+    assert tot.value == 0
+    assert L.ced_render_image_test(C.byref(d), 5, None, None, None, 1, 128, None, 0.0, 1e10, 5e-3, 0.0, 1e-4, 64, None, 0,
+                                   None, None, None, None, None, 0, None, C.byref(tot), None, None) == -1
+
+
+def test_closed_form_skip_matches_sequential_recurrence(oracle):
+    """ced_host_skip_march runs the kernels' skip code on the host: the O(#binades) closed form for
+    cone_angle == 0 must land on exactly the float the oracle's step-by-step loop reaches."""
+    from ced_nerf_amd import _lib
+    L = _lib.lib(); OL = oracle.lib()
+    rng = np.random.default_rng(0)
+    n_bad = 0
+    for step in (5e-3, 1e-3, 0.25, 1e-2, 3.3e-3, 0.1, 2.0 ** -7, 7e-5 * 64):
+        st = float(np.float32(step))
+        for _ in range(1500):
+            t = np.float32(rng.uniform(0, 8) if rng.uniform() < 0.8 else rng.uniform(0, 0.02))
+            if rng.uniform() < 0.05:
+                t = np.float32(0.0)
+            target = np.float32(t + rng.uniform(-0.1, 6) * (1 if rng.uniform() < 0.7 else 0.01))
+            n_bad += L.ced_host_skip_march(float(t), float(target), st, 0.0) != OL.ced_o_skip_march(float(t), float(target), st, 0.0)
+    assert n_bad == 0
+    # cone_angle > 0 takes the sequential path; step_size <= 0 jumps to the target
+    for t, target in ((0.2, 1.7), (0.5, 0.4), (1.0, 3.0)):
+        assert L.ced_host_skip_march(t, target, 1e-3, 0.004) == OL.ced_o_skip_march(t, target, 1e-3, 0.004)
+    assert L.ced_host_skip_march(0.3, 2.5, 0.0, 0.0) == 2.5
 
 
 def _ref_pack(layer_w, n_out_rows, ks, rot=0):

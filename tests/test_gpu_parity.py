@@ -201,6 +201,24 @@ def _packed_problem(n_rays, seed, empty_frac=0.3):
     return packed, t0, t1, sig, rgbs
 
 
+def test_skip_march_closed_form_on_device_paths(oracle):
+    """Long empty runs before the first sample (camera far from a tiny occupied blob, several step
+    sizes): exercises the closed-form empty-space skip inside the marching kernels."""
+    from ced_nerf_amd import nerfacc_api as A
+    b = np.zeros((1, 128, 128, 128), bool); b[0, 60:68, 60:68, 60:68] = True
+    aabbs = np.array([[-1.5, -1.5, -1.5, 1.5, 1.5, 1.5]], np.float32)
+    o, d = random_rays(4000, 21, radius=6.0, spread=0.3)
+    for step in (5e-3, 1e-3, 3.3e-3, 2.0 ** -7):
+        n = o.shape[0]
+        near = np.zeros(n, np.float32); far = np.full(n, 1e10, np.float32)
+        want = oracle.traverse_grids(o, d, b, aabbs, near, far, step, 0.0)
+        i_, s_, term = A.traverse_grids(T(o), T(d), T(b), T(aabbs), T(near), T(far), step, 0.0)
+        assert want["t_starts"].shape[0] > 1000
+        assert_bitexact(N(s_.packed_info), want["packed_info"], f"packed_info step={step}")
+        assert_bitexact(N(i_.vals[i_.is_left]), want["t_starts"], f"t_starts step={step}")
+        assert_bitexact(N(term), want["termination_planes"], f"termination step={step}")
+
+
 def test_compositing_ops(oracle):
     from ced_nerf_amd import nerfacc_api as A, ops, render as R
     packed, t0, t1, sig, rgbs = _packed_problem(3000, 5)
@@ -278,16 +296,25 @@ def _setup(oracle, sc):
                                             ("hypernerf", "trained", (48, 64)), ("dynerf", "trained", (64, 48))])
 def test_render_image_test_parity(oracle, name, regime, wh):
     """a1: render_image_test end to end; per-iteration sample counts bit-exact, pixels <= 1e-4."""
-    from ced_nerf_amd.utils import render_image_test
+    from ced_nerf_amd import ops
+    from ced_nerf_amd.utils import render_image_test, render_image_test_staged
     sc = _scene(name, wh[0], wh[1], regime, log2_hashmap_size=17)
     of, oest, f, est, rays, rk = _setup(oracle, sc)
     max_samples = 256 if regime == "init" else 1024
     trace = []
     w_rgb, w_op, w_dp, w_total = oracle.render_image_test(max_samples, of, oest, sc["origins"], sc["viewdirs"],
                                                           timestamps=sc["timestamps"], trace=trace, **sc["render"])
-    rgb, op, dp, total = render_image_test(max_samples, f, est, rays, timestamps=T(sc["timestamps"]), **rk)
+    tracer = ops.FrameTracer(capacity=1100, with_events=False)
+    rgb, op, dp, total = render_image_test(max_samples, f, est, rays, timestamps=T(sc["timestamps"]), tracer=tracer, **rk)
     assert rgb.shape == (wh[1], wh[0], 3) and op.shape == (wh[1], wh[0], 1) and dp.shape == (wh[1], wh[0], 1)
     assert total == w_total and total > 2000
+    # the image-global schedule (N_alive, N_samples, samples marched) of every iteration, bit-exact
+    assert tracer.iterations() == [dict(n_alive=t["n_alive"], n_samples=t["n_samples"], n_new=t["n_new"]) for t in trace]
+    # the Python-staged loop over the nerfacc-shaped ops renders the same frame
+    s_rgb, s_op, s_dp, s_total = render_image_test_staged(max_samples, f, est, rays, timestamps=T(sc["timestamps"]), **rk)
+    assert s_total == total
+    assert_bitexact(N(s_rgb), N(rgb), "staged vs native rgb"); assert_bitexact(N(s_dp), N(dp), "staged vs native depth")
+    assert_bitexact(N(s_op), N(op), "staged vs native opacity")
     assert np.abs(N(rgb) - w_rgb).max() <= 1e-4
     assert np.abs(N(op) - w_op).max() <= 1e-4
     assert np.abs(N(dp) - w_dp).max() <= 1e-4
