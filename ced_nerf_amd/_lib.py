@@ -54,6 +54,7 @@ _vp, _i64, _i32, _f = C.c_void_p, C.c_int64, C.c_int32, C.c_float
 PROTOTYPES = {
     "ced_version": (C.c_int, []),
     "ced_last_error_string": (C.c_char_p, []),
+    "ced_set_option": (C.c_int, [C.c_char_p, C.c_int]),
     "ced_packed_weight_floats": (_i64, [C.c_int, C.c_int]),
     "ced_pack_field_weights": (C.c_int, [C.c_int, C.c_int] + [_vp] * 10),
     "ced_ray_aabb_intersect": (C.c_int, [_i64, _vp, _vp, _i32, _vp, _f, _f, _f, _vp, _vp, _vp, _vp]),

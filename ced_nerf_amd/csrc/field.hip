@@ -16,6 +16,9 @@
 // The hash gather is laid out in the same fragment geometry: lane group g owns levels
 // {2g, 2g+1, 8+2g, 9+2g} of its 16 samples, so the gathered features land in B-operand order
 // after two such transposes and the 128 gathers per sample are spread over 4 lanes.
+#include <cstdlib>
+#include <cstring>
+
 #include "ced_common.hpp"
 #include "field_args.hpp"
 
@@ -23,9 +26,6 @@ namespace ced {
 
 typedef float f4 __attribute__((ext_vector_type(4)));
 
-constexpr int NT = 4;         // 16-sample MFMA column tiles per wave iteration (64 samples)
-constexpr int FIELD_THREADS = 512;
-constexpr int FIELD_WAVES = FIELD_THREADS / kWave;
 
 // ---- packed weight blob: layer l stored as [nb][ks4][lane 64][4] floats ----------------------
 struct LayerShape { int nb; int ks; };
@@ -64,7 +64,7 @@ __device__ __forceinline__ void transpose4(float &r0, float &r1, float &r2, floa
 
 // D[j][nb] (16 neurons x 16 samples, neurons 16nb+4g+r on lane group g reg r) =
 //     sum_k W[neuron][k] * B[j][k/4] (k = 4S+g on lane group g), ascending k.
-template <int KS, int NB>
+template <int KS, int NB, int NT>
 __device__ __forceinline__ void mlp_layer(const float *__restrict__ wl, int lane, const float (&B)[NT][16],
                                           f4 (&D)[NT][4])
 {
@@ -92,7 +92,7 @@ __device__ __forceinline__ void mlp_layer(const float *__restrict__ wl, int lane
 }
 
 // ReLU (optional) on the accumulator blocks, then transpose them into the next layer's B operand.
-template <int NB, bool RELU>
+template <int NB, bool RELU, int NT>
 __device__ __forceinline__ void to_operand(const f4 (&D)[NT][4], float (&B)[NT][16])
 {
 #pragma unroll
@@ -120,9 +120,9 @@ struct LevelConst {
 
 // Trilinear gather of one level for one point (hash_encoder_half.py:112-161; temporal variant
 // hash_encoder_inter.py:148-197).  x already clamped to [0,1].
-__device__ __forceinline__ void hash_level(const LevelConst &L, const void *__restrict__ table, int table_dtype,
-                                           int temporal, const float (&x)[3], int k_lo, float t_frac, float &f0,
-                                           float &f1)
+template <bool F16, bool TEMPORAL>
+__device__ __forceinline__ void hash_level(const LevelConst &L, const void *__restrict__ table, const float (&x)[3],
+                                           int k_lo, float t_frac, float &f0, float &f1)
 {
     uint32_t g[3];
     float fr[3], om[3];
@@ -154,8 +154,8 @@ __device__ __forceinline__ void hash_level(const LevelConst &L, const void *__re
         w[c] = (wx * wy) * wz;
     }
     float v0[8], v1[8];
-    if (!temporal) {
-        if (table_dtype == 0) {
+    if constexpr (!TEMPORAL) {
+        if constexpr (!F16) {
             const float2 *tb = reinterpret_cast<const float2 *>(table);
 #pragma unroll
             for (int c = 0; c < 8; ++c) { float2 v = tb[e[c]]; v0[c] = v.x; v1[c] = v.y; }
@@ -170,7 +170,7 @@ __device__ __forceinline__ void hash_level(const LevelConst &L, const void *__re
         }
     } else {
         const float omt = 1.0f - t_frac;
-        if (table_dtype == 0) {
+        if constexpr (!F16) {
             const float2 *tb = reinterpret_cast<const float2 *>(table);
 #pragma unroll
             for (int c = 0; c < 8; ++c) {
@@ -228,9 +228,13 @@ __device__ __forceinline__ float time_feature(int idx, int time_mode, float t, f
     return s;
 }
 
-template <bool TE>
-__global__ __launch_bounds__(FIELD_THREADS, 2) void field_kernel(FieldArgs A)
+// NT: 16-sample MFMA column tiles per wave iteration; THREADS: workgroup size (one workgroup per CU)
+template <bool TE, bool F16, bool TEMPORAL, int NT, int THREADS>
+__global__ __launch_bounds__(THREADS) void field_kernel(FieldArgs A)
 {
+    constexpr int FIELD_THREADS = THREADS;
+    constexpr int FIELD_WAVES = THREADS / kWave;
+    constexpr int TILE = 16 * NT;
     using BL = Blob<TE>;
     __shared__ __attribute__((aligned(16))) float lds[BL::TOTAL + 8 * CED_MAX_LEVELS];
     const int tid = threadIdx.x;
@@ -275,17 +279,23 @@ __global__ __launch_bounds__(FIELD_THREADS, 2) void field_kernel(FieldArgs A)
         const int64_t nd = *A.n_dev;
         n_eff = nd < n_eff ? nd : n_eff;
     }
-    const int64_t n_tiles = (n_eff + 63) / 64;
+    const int64_t n_tiles = (n_eff + TILE - 1) / TILE;
     const float extent[3] = { A.aabb[3] - A.aabb[0], A.aabb[4] - A.aabb[1], A.aabb[5] - A.aabb[2] };
 
     for (int64_t tile = (int64_t)blockIdx.x * FIELD_WAVES + wave; tile < n_tiles;
          tile += (int64_t)gridDim.x * FIELD_WAVES) {
+        // Re-derive the LDS weight base every tile through an opaque register: the A fragments sit at
+        // tile-invariant addresses and the compiler would otherwise hoist all ~80 ds_read_b128 out of
+        // the persistent loop and park them in scratch.
+        int lds_off = 0;
+        asm volatile("" : "+v"(lds_off));
+        const float *const lw = lds + lds_off;
         int64_t sidx[NT];
         int64_t ridx[NT];
         float px[NT][3], tq[NT];
 #pragma unroll
         for (int j = 0; j < NT; ++j) {
-            int64_t s = tile * 64 + 16 * j + c;
+            int64_t s = tile * TILE + 16 * j + c;
             s = s < n_eff ? s : n_eff - 1;
             sidx[j] = s;
             if (A.rays_mode) {
@@ -319,13 +329,13 @@ __global__ __launch_bounds__(FIELD_THREADS, 2) void field_kernel(FieldArgs A)
             }
         }
         // --- motion MLP 32-64-64-64-(3|6) ---
-        mlp_layer<8, 4>(lds + BL::M0, lane, B, D);
-        to_operand<4, true>(D, B);
-        mlp_layer<16, 4>(lds + BL::M1, lane, B, D);
-        to_operand<4, true>(D, B);
-        mlp_layer<16, 4>(lds + BL::M2, lane, B, D);
-        to_operand<4, true>(D, B);
-        mlp_layer<16, 1>(lds + BL::M3, lane, B, D);
+        mlp_layer<8, 4, NT>(lw + BL::M0, lane, B, D);
+        to_operand<4, true, NT>(D, B);
+        mlp_layer<16, 4, NT>(lw + BL::M1, lane, B, D);
+        to_operand<4, true, NT>(D, B);
+        mlp_layer<16, 4, NT>(lw + BL::M2, lane, B, D);
+        to_operand<4, true, NT>(D, B);
+        mlp_layer<16, 1, NT>(lw + BL::M3, lane, B, D);
 
         // --- query_move / normalise / selector (model.py:354-383) ---
         float xn[NT][3], mnorm[NT];
@@ -361,11 +371,11 @@ __global__ __launch_bounds__(FIELD_THREADS, 2) void field_kernel(FieldArgs A)
         for (int j = 0; j < NT; ++j) {
             int k_lo = 0;
             float t_frac = 0.0f;
-            if (A.temporal) temporal_keyframe(tq[j], k_lo, t_frac);
+            if constexpr (TEMPORAL) temporal_keyframe(tq[j], k_lo, t_frac);
             float R[8];
 #pragma unroll
             for (int i = 0; i < 4; ++i)
-                hash_level(LC[i], A.table, A.table_dtype, A.temporal, xn[j], k_lo, t_frac, R[2 * i], R[2 * i + 1]);
+                hash_level<F16, TEMPORAL>(LC[i], A.table, xn[j], k_lo, t_frac, R[2 * i], R[2 * i + 1]);
             transpose4(R[0], R[1], R[2], R[3]);
             transpose4(R[4], R[5], R[6], R[7]);
 #pragma unroll
@@ -377,14 +387,14 @@ __global__ __launch_bounds__(FIELD_THREADS, 2) void field_kernel(FieldArgs A)
         }
 
         // --- mlp_base (32|41)-64-16; accumulator row p holds output neuron (p+13)&15 ---
-        mlp_layer<BL::KS_B0, 4>(lds + BL::B0, lane, B, D);
-        to_operand<4, true>(D, B);
-        mlp_layer<16, 1>(lds + BL::B1, lane, B, D);
+        mlp_layer<BL::KS_B0, 4, NT>(lw + BL::B0, lane, B, D);
+        to_operand<4, true, NT>(D, B);
+        mlp_layer<16, 1, NT>(lw + BL::B1, lane, B, D);
 
         const bool store_lane = (g == 0);
 #pragma unroll
         for (int j = 0; j < NT; ++j) {
-            const int64_t s = tile * 64 + 16 * j + c;
+            const int64_t s = tile * TILE + 16 * j + c;
             float sg = det_expf(D[j][0][3] - 1.0f);           // density = trunc_exp(raw - 1) * selector
             sg = sel[j] ? sg : 0.0f;
             if (store_lane && s < n_eff) A.sigma[s] = sg;
@@ -399,7 +409,7 @@ __global__ __launch_bounds__(FIELD_THREADS, 2) void field_kernel(FieldArgs A)
 
         if (A.want_rgb) {
             // --- head input: [SH(4), geo(15)] (model.py:447-459); k = 4S+g ---
-            to_operand<1, false>(D, B);      // B[j][0..3] = accumulator rows 4s+g
+            to_operand<1, false, NT>(D, B);      // B[j][0..3] = accumulator rows 4s+g
 #pragma unroll
             for (int j = 0; j < NT; ++j) {
                 const float geo_tail = (g == 3) ? 0.0f : B[j][0];     // rows 0,1,2 = neurons 13,14,15; row 3 = density
@@ -421,14 +431,14 @@ __global__ __launch_bounds__(FIELD_THREADS, 2) void field_kernel(FieldArgs A)
                 B[j][0] = sh;
                 B[j][4] = geo_tail;
             }
-            mlp_layer<5, 4>(lds + BL::H0, lane, B, D);
-            to_operand<4, true>(D, B);
-            mlp_layer<16, 4>(lds + BL::H1, lane, B, D);
-            to_operand<4, true>(D, B);
-            mlp_layer<16, 1>(lds + BL::H2, lane, B, D);
+            mlp_layer<5, 4, NT>(lw + BL::H0, lane, B, D);
+            to_operand<4, true, NT>(D, B);
+            mlp_layer<16, 4, NT>(lw + BL::H1, lane, B, D);
+            to_operand<4, true, NT>(D, B);
+            mlp_layer<16, 1, NT>(lw + BL::H2, lane, B, D);
 #pragma unroll
             for (int j = 0; j < NT; ++j) {
-                const int64_t s = tile * 64 + 16 * j + c;
+                const int64_t s = tile * TILE + 16 * j + c;
                 float o3[3];
 #pragma unroll
                 for (int a = 0; a < 3; ++a) o3[a] = 1.0f / (1.0f + det_expf(-D[j][0][a]));
@@ -453,6 +463,7 @@ struct HashArgs {
     uint32_t res[CED_MAX_LEVELS], offset[CED_MAX_LEVELS], size[CED_MAX_LEVELS], hashed[CED_MAX_LEVELS];
 };
 
+template <bool F16, bool TEMPORAL>
 __global__ __launch_bounds__(256) void hash_encode_kernel(HashArgs A)
 {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -462,7 +473,7 @@ __global__ __launch_bounds__(256) void hash_encode_kernel(HashArgs A)
     for (int a = 0; a < 3; ++a) x[a] = __builtin_fminf(__builtin_fmaxf(A.x[3 * i + a], 0.0f), 1.0f);
     int k_lo = 0;
     float t_frac = 0.0f;
-    if (A.temporal) temporal_keyframe(A.t ? A.t[i] : 0.0f, k_lo, t_frac);
+    if constexpr (TEMPORAL) temporal_keyframe(A.t ? A.t[i] : 0.0f, k_lo, t_frac);
     float *o = A.out + i * 2 * A.n_levels;
 #pragma unroll
     for (int l = 0; l < CED_MAX_LEVELS; ++l) {
@@ -476,12 +487,15 @@ __global__ __launch_bounds__(256) void hash_encode_kernel(HashArgs A)
             L.size = A.size[l];
             L.hashed = A.hashed[l];
             float f0, f1;
-            hash_level(L, A.table, A.table_dtype, A.temporal, x, k_lo, t_frac, f0, f1);
+            hash_level<F16, TEMPORAL>(L, A.table, x, k_lo, t_frac, f0, f1);
             o[2 * l] = f0;
             o[2 * l + 1] = f1;
         }
     }
 }
+
+// launch-geometry variant of the field kernel (ced_set_option("field_variant", v))
+static int g_field_variant = [] { const char *e = getenv("CED_FIELD_VARIANT"); return e ? atoi(e) : 2; }();
 
 static int validate_hash(const ced_hash_desc *h, const char *who)
 {
@@ -530,17 +544,49 @@ int launch_field(const ced_field_desc *d, FieldArgs &A, void *stream)
         A.size[l] = d->hash.size[l];
         A.hashed[l] = d->hash.hashed[l];
     }
-    const int64_t n_tiles = (A.n + 63) / 64;
-    int64_t blocks = (n_tiles + FIELD_WAVES - 1) / FIELD_WAVES;
-    if (blocks > 256) blocks = 256;     // one resident workgroup per CU, persistent over tiles
-    if (d->time_mode)
-        hipLaunchKernelGGL(field_kernel<true>, dim3((unsigned)blocks), dim3(FIELD_THREADS), 0, (hipStream_t)stream, A);
-    else
-        hipLaunchKernelGGL(field_kernel<false>, dim3((unsigned)blocks), dim3(FIELD_THREADS), 0, (hipStream_t)stream, A);
+    const int variant = g_field_variant;
+    auto launch = [&](auto kernel, int nt, int threads) {
+        const int64_t n_tiles = (A.n + 16 * nt - 1) / (16 * nt);
+        const int waves = threads / 64;
+        int64_t blocks = (n_tiles + waves - 1) / waves;
+        if (blocks > 256) blocks = 256;     // one resident workgroup per CU, persistent over tiles
+        hipLaunchKernelGGL(kernel, dim3((unsigned)blocks), dim3(threads), 0, (hipStream_t)stream, A);
+    };
+    const int sel = (d->time_mode ? 1 : 0) | (A.table_dtype ? 2 : 0) | (A.temporal ? 4 : 0);
+#define CED_FIELD_CASE(NT_, TH_)                                                                                \
+    switch (sel) {                                                                                              \
+    case 0: launch(field_kernel<false, false, false, NT_, TH_>, NT_, TH_); break;                               \
+    case 1: launch(field_kernel<true, false, false, NT_, TH_>, NT_, TH_); break;                                \
+    case 2: launch(field_kernel<false, true, false, NT_, TH_>, NT_, TH_); break;                                \
+    case 3: launch(field_kernel<true, true, false, NT_, TH_>, NT_, TH_); break;                                 \
+    case 4: launch(field_kernel<false, false, true, NT_, TH_>, NT_, TH_); break;                                \
+    case 5: launch(field_kernel<true, false, true, NT_, TH_>, NT_, TH_); break;                                 \
+    case 6: launch(field_kernel<false, true, true, NT_, TH_>, NT_, TH_); break;                                 \
+    default: launch(field_kernel<true, true, true, NT_, TH_>, NT_, TH_); break;                                 \
+    }
+    switch (variant) {
+    case 1: CED_FIELD_CASE(2, 512) break;
+    case 2: CED_FIELD_CASE(2, 768) break;
+    case 3: CED_FIELD_CASE(2, 1024) break;
+    default: CED_FIELD_CASE(4, 512) break;
+    }
+#undef CED_FIELD_CASE
     return check_launch("field_forward");
 }
 
 }  // namespace ced
+
+extern "C" int ced_set_option(const char *key, int value)
+{
+    CED_REQUIRE(key != nullptr, "set_option: null key");
+    if (strcmp(key, "field_variant") == 0) {
+        CED_REQUIRE(value >= 0 && value <= 3, "set_option: field_variant must be 0..3");
+        ced::g_field_variant = value;
+        return CED_OK;
+    }
+    ced::set_error("set_option: unknown key '%s'", key);
+    return CED_E_INVALID;
+}
 
 extern "C" int64_t ced_packed_weight_floats(int use_div_offsets, int time_mode)
 {
@@ -652,6 +698,13 @@ extern "C" int ced_hash_encode(const ced_hash_desc *desc, int64_t n, const float
         A.scale[l] = desc->scale[l]; A.res[l] = desc->res[l]; A.offset[l] = desc->offset[l];
         A.size[l] = desc->size[l]; A.hashed[l] = desc->hashed[l];
     }
-    hipLaunchKernelGGL(ced::hash_encode_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, A);
+    const dim3 grid((unsigned)((n + 255) / 256)), block(256);
+    const int sel = (A.table_dtype ? 1 : 0) | (A.temporal ? 2 : 0);
+    switch (sel) {
+    case 0: hipLaunchKernelGGL((ced::hash_encode_kernel<false, false>), grid, block, 0, (hipStream_t)stream, A); break;
+    case 1: hipLaunchKernelGGL((ced::hash_encode_kernel<true, false>), grid, block, 0, (hipStream_t)stream, A); break;
+    case 2: hipLaunchKernelGGL((ced::hash_encode_kernel<false, true>), grid, block, 0, (hipStream_t)stream, A); break;
+    default: hipLaunchKernelGGL((ced::hash_encode_kernel<true, true>), grid, block, 0, (hipStream_t)stream, A); break;
+    }
     return ced::check_launch("hash_encode");
 }

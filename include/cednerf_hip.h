@@ -72,6 +72,10 @@ typedef struct ced_field_desc {
 int ced_version(void);
 const char *ced_last_error_string(void);
 
+/* Tuning knobs (process-wide).  "field_variant": launch geometry of the fused field kernel,
+ * 0 = 4 column tiles x 512 threads, 1 = 2 x 512, 2 = 2 x 768, 3 = 2 x 1024 (results are identical). */
+int ced_set_option(const char *key, int value);
+
 /* Number of floats in the packed (MFMA-fragment-order) weight blob. */
 int64_t ced_packed_weight_floats(int use_div_offsets, int time_mode);
 

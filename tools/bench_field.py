@@ -1,0 +1,41 @@
+"""Micro-benchmark of the fused field kernel on a realistic, ray-coherent sample stream
+(all samples marched through the occupancy grid of the 800x800 D-NeRF-shaped frame)."""
+import os, sys, time, json
+import numpy as np, torch
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from ced_nerf_amd import _lib, ops, synthetic as S
+from ced_nerf_amd.model import DNGPradianceField
+from ced_nerf_amd.nerfacc_api import march_packed
+
+dev = "cuda:0"
+T = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+scene = sys.argv[1] if len(sys.argv) > 1 else "dnerf"
+dtype = np.float16 if (len(sys.argv) > 2 and sys.argv[2] == "f16") else np.float32
+W = H = 800 if scene == "dnerf" else 600
+sc = S.make_scene(scene, W, H, "trained", table_dtype=dtype)
+cfg = sc["cfg"]
+f = DNGPradianceField.from_params(sc["params"], dev).eval()
+o = T(sc["origins"]).reshape(-1, 3); d = T(sc["viewdirs"]).reshape(-1, 3)
+from ced_nerf_amd.nerfacc_api import OccGridEstimator
+est = OccGridEstimator(cfg["aabb"], 128, cfg["grid_levels"]).to(dev); est.set_binaries(T(sc["binaries"]))
+n = o.shape[0]
+near = torch.full((n,), cfg["near_plane"], device=dev); far = torch.full((n,), cfg["far_plane"], device=dev)
+t0, t1, ri, packed, _ = march_packed(o, d, est.binaries, est.aabbs, near, far, cfg["render_step_size"], cfg["cone_angle"])
+ts = T(sc["timestamps"]).reshape(-1)
+N = t0.shape[0]
+print("samples", N)
+res = {}
+for variant in (0, 1, 2, 3):
+    _lib.check(_lib.lib().ced_set_option(b"field_variant", variant))
+    for want_rgb in (True, False):
+        for _ in range(2):
+            ops.field_forward_rays(f._descriptor(), o, d, ri, t0, t1, ts, False, want_rgb)
+        torch.cuda.synchronize()
+        e0 = torch.cuda.Event(enable_timing=True); e1 = torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(5):
+            ops.field_forward_rays(f._descriptor(), o, d, ri, t0, t1, ts, False, want_rgb)
+        e1.record(); torch.cuda.synchronize()
+        ms = e0.elapsed_time(e1) / 5
+        res[(variant, want_rgb)] = ms
+        print(f"variant {variant} rgb={want_rgb}: {ms:.3f} ms  {N/ms/1e6:.1f} Msamples/ms -> {N/ms*1e3/1e9:.3f} Gsamples/s, {N*38e3/ms*1e3/1e12:.1f} TFLOP/s(alg)")
