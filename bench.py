@@ -37,12 +37,14 @@ def parse():
     ap.add_argument("--regime", default="trained")
     ap.add_argument("--max-samples", type=int, default=1024)
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-stride", type=int, default=3, help="pixel stride of the CPU-baseline ray sample")
+    ap.add_argument("--cpu-stride", type=int, default=1, help="pixel stride of the CPU-baseline ray sample")
     return ap.parse_args()
 
 
 def cpu_baseline(sc, args):
     """The CPU oracle (a scalar C port, OpenMP over rays) on a strided sample of the same frame."""
+    cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    os.environ.setdefault("OMP_NUM_THREADS", str(cores))          # before the OpenMP runtime loads
     from oracle import oracle as O
     O.build()
     cfg = sc["cfg"]
@@ -53,7 +55,7 @@ def cpu_baseline(sc, args):
     t0 = time.perf_counter()
     out = O.render_image_test(args.max_samples, of, oest, o, d, timestamps=sc["timestamps"], **sc["render"])
     dt = time.perf_counter() - t0
-    cores = int(os.environ.get("OMP_NUM_THREADS", os.cpu_count() or 1))
+    cores = int(os.environ["OMP_NUM_THREADS"])
     return {"value": out[3] / dt, "unit": "samples/s", "cores": cores, "kind": "port",
             "rays_per_sec": o.shape[0] * o.shape[1] / dt,
             "sample": f"every {s}th pixel in x and y of the same {args.width}x{args.height} frame "

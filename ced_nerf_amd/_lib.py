@@ -12,7 +12,7 @@ from typing import List, Optional
 
 _PKG = os.path.dirname(os.path.abspath(__file__))
 _ROOT = os.path.dirname(_PKG)
-LIB_PATH = os.path.join(_PKG, "libcednerf_hip.so")
+LIB_PATH = os.environ.get("CED_NERF_LIB", os.path.join(_PKG, "libcednerf_hip.so"))
 SOURCES = ["runtime.hip", "march.hip", "composite.hip", "field.hip", "frame.hip"]
 HIPCC_FLAGS = ["--offload-arch=gfx950", "-O3", "-ffp-contract=off", "-fPIC", "-shared", "-std=c++17"]
 MAX_LEVELS = 16

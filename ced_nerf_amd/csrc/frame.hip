@@ -104,13 +104,20 @@ struct MarchArgs {
     unsigned long long *counter;   // samples reserved so far in this iteration
 };
 
-// One wave (64 rays) per workgroup; dynamic LDS = 64 * limit * 8 bytes, slot-major so a wave's
-// stores of slot i are 512 contiguous bytes (conflict-free).
-__global__ __launch_bounds__(64) void march_alloc_kernel(MarchArgs A)
+// Workgroup of T threads (T/64 waves).  Each ray marches once and stages its (t_start, t_end) pairs
+// in LDS (dynamic LDS = T * limit * 8 bytes, slot-major per wave so a wave's stores of slot i are 512
+// contiguous bytes); the workgroup then reserves ONE contiguous output range with a single returning
+// atomic -- a returning atomic on one word sustains only ~88 ops/us on this chip, so one per wave
+// (10^4 per launch) would cost more than the marching itself.
+__global__ void march_alloc_kernel(MarchArgs A)
 {
-    extern __shared__ __attribute__((aligned(16))) float2 stage[];
-    const int lane = threadIdx.x;
-    const int64_t r = (int64_t)blockIdx.x * 64 + lane;
+    extern __shared__ __attribute__((aligned(16))) float2 stage_all[];
+    __shared__ int wave_tot[16];
+    __shared__ long long block_base;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, n_waves = blockDim.x >> 6;
+    const int limit = A.grid.limit;
+    float2 *stage = stage_all + (size_t)wave * limit * 64;
+    const int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     int n = 0;
     if (r < A.n_rays && A.ray_mask[r]) {
         const float o[3] = { A.rays_o[3 * r], A.rays_o[3 * r + 1], A.rays_o[3 * r + 2] };
@@ -122,18 +129,22 @@ __global__ __launch_bounds__(64) void march_alloc_kernel(MarchArgs A)
             A.hits + r * m, [&](int i, float t0, float t1) { stage[i * 64 + lane] = make_float2(t0, t1); }, t_term);
         A.near_planes[r] = t_term;
     }
-    // wave-inclusive prefix sum of the counts, one atomic for the whole wave
+    // wave-inclusive prefix sum of the counts
     int incl = n;
 #pragma unroll
     for (int off = 1; off < 64; off <<= 1) {
         int v = __shfl_up(incl, off, 64);
         if (lane >= off) incl += v;
     }
-    const int total = __shfl(incl, 63, 64);
-    unsigned long long wave_base = 0;
-    if (lane == 0 && total > 0) wave_base = atomicAdd(A.counter, (unsigned long long)total);
-    wave_base = __shfl(wave_base, 0, 64);
-    const int64_t start = (int64_t)wave_base + (incl - n);
+    if (lane == 63) wave_tot[wave] = incl;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        int run = 0;
+        for (int w = 0; w < n_waves; ++w) { int t = wave_tot[w]; wave_tot[w] = run; run += t; }
+        block_base = run > 0 ? (long long)atomicAdd(A.counter, (unsigned long long)run) : 0;
+    }
+    __syncthreads();
+    const int64_t start = (int64_t)block_base + wave_tot[wave] + (incl - n);
     if (r < A.n_rays) {
         A.packed[2 * r] = (int32_t)start;
         A.packed[2 * r + 1] = n;
@@ -155,8 +166,9 @@ __global__ __launch_bounds__(256) void frame_composite_kernel(int64_t n_rays, co
                                                               float *__restrict__ opacity, float *__restrict__ depth,
                                                               float opc_thres, int n_samples_iter,
                                                               uint8_t *__restrict__ ray_mask,
-                                                              unsigned long long *__restrict__ stats)
+                                                              long long *__restrict__ block_stats)
 {
+    __shared__ int red[2][4];
     int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     int cnt = 0;
     bool alive = false;
@@ -168,7 +180,33 @@ __global__ __launch_bounds__(256) void frame_composite_kernel(int64_t n_rays, co
             const float prefix = 1.0f - op;
             float c0 = rgb[3 * r], c1 = rgb[3 * r + 1], c2 = rgb[3 * r + 2], dp = depth[r];
             float acc = 0.0f;
-            for (int i = s0; i < s0 + cnt; ++i) {
+            // Samples are consumed strictly in order (the per-ray sums are sequential by contract), but
+            // their loads are issued kU at a time so one memory round trip feeds kU samples.
+            constexpr int kU = 4;
+            int i = s0;
+            const int end = s0 + cnt;
+            for (; i + kU <= end; i += kU) {
+                float ts[kU], te[kU], sg[kU], cr[kU], cg[kU], cb[kU];
+#pragma unroll
+                for (int u = 0; u < kU; ++u) {
+                    ts[u] = t0[i + u]; te[u] = t1[i + u]; sg[u] = sig[i + u];
+                    cr[u] = rgbs[3 * (i + u)]; cg[u] = rgbs[3 * (i + u) + 1]; cb[u] = rgbs[3 * (i + u) + 2];
+                }
+#pragma unroll
+                for (int u = 0; u < kU; ++u) {
+                    float sd = sg[u] * (te[u] - ts[u]);
+                    float a = 1.0f - det_expf(-sd);
+                    float t = det_expf(-acc) * prefix;
+                    float w = t * a;
+                    c0 = c0 + w * cr[u];
+                    c1 = c1 + w * cg[u];
+                    c2 = c2 + w * cb[u];
+                    op = op + w;
+                    dp = dp + w * ((ts[u] + te[u]) / 2.0f);
+                    acc = acc + sd;
+                }
+            }
+            for (; i < end; ++i) {
                 float ts = t0[i], te = t1[i];
                 float sd = sig[i] * (te - ts);
                 float a = 1.0f - det_expf(-sd);
@@ -188,14 +226,18 @@ __global__ __launch_bounds__(256) void frame_composite_kernel(int64_t n_rays, co
         alive = (op <= opc_thres) && (cnt == n_samples_iter);
         ray_mask[r] = alive ? 1 : 0;
     }
+    // (alive rays, samples) of this workgroup -> block_stats[blockIdx]; the host adds the partials up
+    // (no atomics: thousands of returning atomics on one word would serialise)
     const unsigned long long ballot = __ballot(alive);
     int c = cnt;
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) c += __shfl_down(c, off, 64);
-    if ((threadIdx.x & 63) == 0) {
-        const int n_alive = __builtin_popcountll(ballot);
-        if (n_alive) atomicAdd(&stats[0], (unsigned long long)n_alive);
-        if (c) atomicAdd(&stats[1], (unsigned long long)c);
+    const int wave = threadIdx.x >> 6;
+    if ((threadIdx.x & 63) == 0) { red[0][wave] = __builtin_popcountll(ballot); red[1][wave] = c; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        block_stats[2 * blockIdx.x] = red[0][0] + red[0][1] + red[0][2] + red[0][3];
+        block_stats[2 * blockIdx.x + 1] = red[1][0] + red[1][1] + red[1][2] + red[1][3];
     }
 }
 
@@ -219,7 +261,8 @@ static inline size_t align_up(size_t x) { return (x + 255) & ~(size_t)255; }
 
 struct FrameWorkspace {
     float *t_sorted; int64_t *t_indices; uint8_t *hits; float *near; uint8_t *mask; int32_t *packed;
-    unsigned long long *stats;      // [iters+1][4]: alive, samples, reserved, pad
+    unsigned long long *counters;   // [iters+1] samples reserved by the marching kernel of each iteration
+    long long *block_stats;         // [ceil(n/256)][2] (alive, samples) partials of the compositing kernel
     float *t0, *t1; int32_t *ridx; float *sigma, *rgbs;
     size_t bytes;
 };
@@ -235,7 +278,8 @@ static FrameWorkspace carve(void *base, int64_t n, int m, int64_t cap, int max_i
     w.near = (float *)take((size_t)n * 4);
     w.mask = (uint8_t *)take((size_t)n);
     w.packed = (int32_t *)take((size_t)n * 8);
-    w.stats = (unsigned long long *)take((size_t)(max_iters + 1) * 32);
+    w.counters = (unsigned long long *)take((size_t)(max_iters + 1) * 8);
+    w.block_stats = (long long *)take((size_t)((n + 255) / 256) * 16);
     w.t0 = (float *)take((size_t)cap * 4);
     w.t1 = (float *)take((size_t)cap * 4);
     w.ridx = (int32_t *)take((size_t)cap * 4);
@@ -284,10 +328,18 @@ extern "C" int ced_render_image_test(const ced_field_desc *field, int64_t n_rays
     CED_REQUIRE((int64_t)W.bytes <= workspace_bytes, "render_image_test: workspace too small (%lld < %lld bytes)",
                 (long long)workspace_bytes, (long long)W.bytes);
     const dim3 blk(256), grd((unsigned)((n_rays + 255) / 256));
+    const int64_t n_blocks = (n_rays + 255) / 256;
+    static bool lds_attr_set = false;
+    if (!lds_attr_set) {        // the marching kernel stages up to 128 KB of samples per workgroup
+        if (hipFuncSetAttribute(reinterpret_cast<const void *>(march_alloc_kernel),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024) != hipSuccess)
+            return check_launch("render_image_test (LDS attribute)");
+        lds_attr_set = true;
+    }
 
     hipLaunchKernelGGL(frame_prep_kernel, grd, blk, 0, stream, n_rays, rays_o, rays_d, (int)n_grids, aabbs, near_plane,
                        W.t_sorted, W.t_indices, W.hits, W.near, W.mask, rgb, opacity, depth);
-    if (hipMemsetAsync(W.stats, 0, (size_t)(max_samples + 2) * 32, stream) != hipSuccess)
+    if (hipMemsetAsync(W.counters, 0, (size_t)(max_samples + 2) * 8, stream) != hipSuccess)
         return check_launch("render_image_test (memset)");
     int rc = check_launch("render_image_test (prep)");
     if (rc) return rc;
@@ -300,19 +352,21 @@ extern "C" int ced_render_image_test(const ced_field_desc *field, int64_t n_rays
         int n_samples = (int)(q < 64 ? q : 64);
         if (n_samples < min_samples) n_samples = min_samples;
         iter_samples += n_samples;
-        unsigned long long *st = W.stats + (size_t)it * 4;
+        unsigned long long *counter = W.counters + it;
 
         MarchArgs M{ n_rays, rays_o, rays_d,
                      GridSpec{ binaries, aabbs, n_grids, res, step_size, cone_angle, n_samples },
-                     W.near, far_plane, W.mask, W.t_sorted, W.t_indices, W.hits, W.t0, W.t1, W.ridx, W.packed, st + 2 };
-        hipLaunchKernelGGL(march_alloc_kernel, dim3((unsigned)((n_rays + 63) / 64)), dim3(64),
-                           (size_t)64 * n_samples * sizeof(float2), stream, M);
+                     W.near, far_plane, W.mask, W.t_sorted, W.t_indices, W.hits, W.t0, W.t1, W.ridx, W.packed, counter };
+        // as many rays per workgroup as 128 KB of sample staging allow: fewer, larger reservations
+        const int threads = n_samples <= 16 ? 1024 : (n_samples <= 32 ? 512 : 256);
+        hipLaunchKernelGGL(march_alloc_kernel, dim3((unsigned)((n_rays + threads - 1) / threads)), dim3(threads),
+                           (size_t)threads * n_samples * sizeof(float2), stream, M);
         rc = check_launch("render_image_test (march)");
         if (rc) return rc;
 
         FieldArgs F{};
         F.n = n_alive * n_samples;          // host-side upper bound; the kernel reads the exact count
-        F.n_dev = reinterpret_cast<const int64_t *>(st + 2);
+        F.n_dev = reinterpret_cast<const int64_t *>(counter);
         F.rays_o = rays_o; F.rays_d = rays_d; F.ray_idx32 = W.ridx;
         F.t0 = W.t0; F.t1 = W.t1; F.timestamps = timestamps;
         F.rays_mode = 1; F.t_per_ray = t_per_ray ? 1 : 0; F.want_rgb = 1;
@@ -323,19 +377,21 @@ extern "C" int ced_render_image_test(const ced_field_desc *field, int64_t n_rays
         if (trace && it < trace->capacity && trace->field_end) hipEventRecord((hipEvent_t)trace->field_end[it], stream);
 
         hipLaunchKernelGGL(frame_composite_kernel, grd, blk, 0, stream, n_rays, W.packed, W.t0, W.t1, W.sigma, W.rgbs, rgb,
-                           opacity, depth, opc_thres, n_samples, W.mask, st);
+                           opacity, depth, opc_thres, n_samples, W.mask, W.block_stats);
         rc = check_launch("render_image_test (composite)");
         if (rc) return rc;
-        if (hipMemcpyAsync(host_stats, st, 16, hipMemcpyDeviceToHost, stream) != hipSuccess ||
+        if (hipMemcpyAsync(host_stats, W.block_stats, (size_t)n_blocks * 16, hipMemcpyDeviceToHost, stream) != hipSuccess ||
             hipStreamSynchronize(stream) != hipSuccess)
             return check_launch("render_image_test (stats copy)");
+        int64_t alive_next = 0, samples_it = 0;
+        for (int64_t b = 0; b < n_blocks; ++b) { alive_next += host_stats[2 * b]; samples_it += host_stats[2 * b + 1]; }
         if (trace && it < trace->capacity) {
             if (trace->iter_alive) trace->iter_alive[it] = n_alive;
             if (trace->iter_n_samples) trace->iter_n_samples[it] = n_samples;
-            if (trace->iter_samples) trace->iter_samples[it] = host_stats[1];
+            if (trace->iter_samples) trace->iter_samples[it] = samples_it;
         }
-        n_alive = host_stats[0];
-        total += host_stats[1];
+        n_alive = alive_next;
+        total += samples_it;
         ++it;
     }
     if (trace) trace->n_iters = it;

@@ -93,7 +93,10 @@ struct GridSpec {
     int limit;                 // <= 0: unlimited
 };
 
-constexpr int kLook = 4;       // DDA look-ahead (cells whose occupancy bytes are fetched together)
+#ifndef CED_KLOOK
+#define CED_KLOOK 8
+#endif
+constexpr int kLook = CED_KLOOK;   // DDA look-ahead (cells whose occupancy bytes are fetched together)
 
 #if defined(__HIPCC__)
 // Traverses one ray; calls emit(i, t_start, t_end) for sample i = 0.. in order.  Returns the
@@ -155,33 +158,38 @@ __device__ __forceinline__ int traverse_ray(const GridSpec &G, const float (&o)[
         // t_last += dt does not depend on where the intermediate boundaries are.
         bool dda_done = false, stop = false, has_pending = false;
         float pending = 0.0f;
+        int safe_cell = (cur[0] * res + cur[1]) * res + cur[2];
         while (!dda_done && !stop) {
             float tt[kLook];
             int cellv[kLook];
             bool valid[kLook];
+            // branch-free look-ahead: predicated selects only, so the kLook occupancy loads below are
+            // independent instructions in flight together (a data-dependent branch per cell would
+            // serialise them behind s_waitcnt)
 #pragma unroll
             for (int b = 0; b < kLook; ++b) {
-                valid[b] = !dda_done;
+                const bool live = !dda_done;
+                valid[b] = live;
                 tt[b] = fminf(fminf(tdist[0], fminf(tdist[1], tdist[2])), this_tmax);
-                cellv[b] = (cur[0] * res + cur[1]) * res + cur[2];
-                if (!dda_done) {
-                    int ax;
-                    if (tdist[0] < tdist[1] && tdist[0] < tdist[2]) ax = 0;
-                    else if (tdist[1] < tdist[2]) ax = 1;
-                    else ax = 2;
-#pragma unroll
-                    for (int a = 0; a < 3; ++a) {
-                        if (a == ax) {
-                            cur[a] += stp[a];
-                            tdist[a] += delta[a];
-                            dda_done = (cur[a] == ovf[a]);
-                        }
-                    }
-                }
+                const int cell = (cur[0] * res + cur[1]) * res + cur[2];
+                safe_cell = live ? cell : safe_cell;            // never form an out-of-grid address
+                cellv[b] = safe_cell;
+                const bool sx = (tdist[0] < tdist[1]) && (tdist[0] < tdist[2]);
+                const bool sy = !sx && (tdist[1] < tdist[2]);
+                const bool sz = !sx && !sy;
+                const float nx = tdist[0] + delta[0], ny = tdist[1] + delta[1], nz = tdist[2] + delta[2];
+                tdist[0] = (live && sx) ? nx : tdist[0];
+                tdist[1] = (live && sy) ? ny : tdist[1];
+                tdist[2] = (live && sz) ? nz : tdist[2];
+                cur[0] += (live && sx) ? stp[0] : 0;
+                cur[1] += (live && sy) ? stp[1] : 0;
+                cur[2] += (live && sz) ? stp[2] : 0;
+                const bool over = (sx && cur[0] == ovf[0]) || (sy && cur[1] == ovf[1]) || (sz && cur[2] == ovf[2]);
+                dda_done = dda_done || (live && over);
             }
             uint8_t occ[kLook];
 #pragma unroll
-            for (int b = 0; b < kLook; ++b) occ[b] = valid[b] ? grid[cellv[b]] : (uint8_t)0;
+            for (int b = 0; b < kLook; ++b) occ[b] = grid[cellv[b]];
 #pragma unroll
             for (int b = 0; b < kLook; ++b) {
                 if (!valid[b] || stop) continue;

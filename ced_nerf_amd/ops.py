@@ -323,8 +323,10 @@ def render_image_test_native(desc: _lib.FieldDesc, rays_o, rays_d, binaries, aab
         raise ValueError("render_image_test: unsupported sizes")
     key = (dev.index, torch.cuda.current_stream().cuda_stream)
     ws = _frame_ws.get(key)
-    if ws is None or ws[0].numel() < need:
-        ws = (torch.empty((max(need, 1),), device=dev, dtype=torch.uint8), torch.zeros((4,), dtype=torch.int64).pin_memory())
+    n_host = 2 * ((n + 255) // 256) + 2
+    if ws is None or ws[0].numel() < need or ws[1].numel() < n_host:
+        ws = (torch.empty((max(need, 1),), device=dev, dtype=torch.uint8),
+              torch.zeros((n_host,), dtype=torch.int64).pin_memory())
         _frame_ws[key] = ws
     rgb = torch.empty((n, 3), device=dev, dtype=torch.float32)
     opacity = torch.empty((n, 1), device=dev, dtype=torch.float32)
