@@ -72,7 +72,7 @@ PROTOTYPES = {
     "ced_composite_step": (C.c_int, [_i64, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _f, _i32, _vp, _vp, _vp]),
     "ced_composite_test": (C.c_int, [_i64, _vp, _vp, _vp, _vp, _vp, _vp, _f, _f, _vp, _vp, _vp, _vp]),
     "ced_finalize_pixels": (C.c_int, [_i64, _vp, _vp, _vp, _vp, _vp]),
-    "ced_render_image_test_workspace_bytes": (_i64, [_i64, _i32, _f, _i32]),
+    "ced_render_image_test_workspace_bytes": (_i64, [_i64, _i32, _i32, _f, _i32]),
     "ced_render_image_test": (C.c_int, [C.POINTER(FieldDesc), _i64, _vp, _vp, _vp, _i32, _i32, _vp, _f, _f, _f, _f, _f,
                                         _i32, _vp, _i32, _vp, _vp, _vp, _vp, _vp, _i64, _vp, C.POINTER(_i64),
                                         C.POINTER(FrameTrace), _vp]),

@@ -494,6 +494,8 @@ __global__ __launch_bounds__(256) void hash_encode_kernel(HashArgs A)
     }
 }
 
+bool g_march_early_out = true;    // frame renderer: conservative brick-level early-out (ced_set_option)
+
 // launch-geometry variant of the field kernel (ced_set_option("field_variant", v))
 static int g_field_variant = [] { const char *e = getenv("CED_FIELD_VARIANT"); return e ? atoi(e) : 2; }();
 
@@ -579,6 +581,10 @@ int launch_field(const ced_field_desc *d, FieldArgs &A, void *stream)
 extern "C" int ced_set_option(const char *key, int value)
 {
     CED_REQUIRE(key != nullptr, "set_option: null key");
+    if (strcmp(key, "march_early_out") == 0) {
+        ced::g_march_early_out = value != 0;
+        return CED_OK;
+    }
     if (strcmp(key, "field_variant") == 0) {
         CED_REQUIRE(value >= 0 && value <= 3, "set_option: field_variant must be 0..3");
         ced::g_field_variant = value;

@@ -26,6 +26,8 @@ struct FieldArgs {
     uint32_t res[CED_MAX_LEVELS], offset[CED_MAX_LEVELS], size[CED_MAX_LEVELS], hashed[CED_MAX_LEVELS];
 };
 
+extern bool g_march_early_out;
+
 // Fills the field/hash parts of A from the descriptor, validates, and launches on `stream`.
 int launch_field(const ced_field_desc *d, FieldArgs &A, void *stream);
 

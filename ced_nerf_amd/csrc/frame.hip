@@ -88,6 +88,37 @@ __global__ __launch_bounds__(256) void frame_prep_kernel(int64_t n_rays, const f
     depth[r] = 0.0f;
 }
 
+// brick_any[b] = any occupied cell in brick b (kBrick^3 cells).  One 64-lane wave per brick: lane
+// (x, y) ORs the 8 contiguous z bytes of its row, then a wave-wide ballot.
+__global__ __launch_bounds__(64) void brick_any_kernel(const uint8_t *__restrict__ binaries, int m, int res, int nb,
+                                                       uint8_t *__restrict__ any)
+{
+    const int idx = blockIdx.x;
+    const int bz = idx % nb, by = (idx / nb) % nb, bx = (idx / (nb * nb)) % nb, lvl = idx / (nb * nb * nb);
+    const uint8_t *g = binaries + (size_t)lvl * res * res * res;
+    const int x = bx * kBrick + (threadIdx.x >> 3), y = by * kBrick + (threadIdx.x & 7);
+    uint8_t acc = 0;
+    if (x < res && y < res)
+        for (int z = bz * kBrick; z < min((bz + 1) * kBrick, res); ++z) acc |= g[((size_t)x * res + y) * res + z];
+    const unsigned long long any_lane = __ballot(acc != 0);
+    if (threadIdx.x == 0) any[idx] = any_lane ? 1 : 0;
+}
+
+// dilated[b] = any of the 3x3x3 bricks around b
+__global__ __launch_bounds__(256) void brick_dilate_kernel(const uint8_t *__restrict__ any, int m, int nb,
+                                                           uint8_t *__restrict__ dil)
+{
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= m * nb * nb * nb) return;
+    const int bz = idx % nb, by = (idx / nb) % nb, bx = (idx / (nb * nb)) % nb, lvl = idx / (nb * nb * nb);
+    const uint8_t *a = any + (size_t)lvl * nb * nb * nb;
+    uint8_t acc = 0;
+    for (int x = max(bx - 1, 0); x <= min(bx + 1, nb - 1); ++x)
+        for (int y = max(by - 1, 0); y <= min(by + 1, nb - 1); ++y)
+            for (int z = max(bz - 1, 0); z <= min(bz + 1, nb - 1); ++z) acc |= a[(x * nb + y) * nb + z];
+    dil[idx] = acc;
+}
+
 struct MarchArgs {
     int64_t n_rays;
     const float *rays_o, *rays_d;
@@ -264,10 +295,11 @@ struct FrameWorkspace {
     unsigned long long *counters;   // [iters+1] samples reserved by the marching kernel of each iteration
     long long *block_stats;         // [ceil(n/256)][2] (alive, samples) partials of the compositing kernel
     float *t0, *t1; int32_t *ridx; float *sigma, *rgbs;
+    uint8_t *brick_any, *brick_dil;
     size_t bytes;
 };
 
-static FrameWorkspace carve(void *base, int64_t n, int m, int64_t cap, int max_iters)
+static FrameWorkspace carve(void *base, int64_t n, int m, int64_t cap, int max_iters, int res)
 {
     FrameWorkspace w{};
     size_t off = 0;
@@ -285,6 +317,9 @@ static FrameWorkspace carve(void *base, int64_t n, int m, int64_t cap, int max_i
     w.ridx = (int32_t *)take((size_t)cap * 4);
     w.sigma = (float *)take((size_t)cap * 4);
     w.rgbs = (float *)take((size_t)cap * 12);
+    const int nb = (res + kBrick - 1) / kBrick;
+    w.brick_any = (uint8_t *)take((size_t)m * nb * nb * nb);
+    w.brick_dil = (uint8_t *)take((size_t)m * nb * nb * nb);
     w.bytes = off;
     return w;
 }
@@ -293,12 +328,12 @@ static inline int min_samples_of(float cone_angle) { return cone_angle == 0.0f ?
 
 }  // namespace ced
 
-extern "C" int64_t ced_render_image_test_workspace_bytes(int64_t n_rays, int32_t n_grids, float cone_angle,
-                                                         int32_t max_samples)
+extern "C" int64_t ced_render_image_test_workspace_bytes(int64_t n_rays, int32_t n_grids, int32_t res,
+                                                         float cone_angle, int32_t max_samples)
 {
-    if (n_rays < 0 || n_grids < 1 || n_grids > ced::kMaxGrids || max_samples < 0) return -1;
+    if (n_rays < 0 || n_grids < 1 || n_grids > ced::kMaxGrids || res < 1 || res > 1024 || max_samples < 0) return -1;
     const int64_t cap = n_rays * ced::min_samples_of(cone_angle);
-    return (int64_t)ced::carve(nullptr, n_rays, n_grids, cap, max_samples + 1).bytes;
+    return (int64_t)ced::carve(nullptr, n_rays, n_grids, cap, max_samples + 1, res).bytes;
 }
 
 extern "C" int ced_render_image_test(const ced_field_desc *field, int64_t n_rays, const float *rays_o,
@@ -313,7 +348,7 @@ extern "C" int ced_render_image_test(const ced_field_desc *field, int64_t n_rays
     using namespace ced;
     hipStream_t stream = (hipStream_t)stream_;
     CED_REQUIRE(field != nullptr, "render_image_test: null field descriptor");
-    CED_REQUIRE(n_rays >= 0 && n_grids >= 1 && n_grids <= kMaxGrids && res >= 1, "render_image_test: bad sizes");
+    CED_REQUIRE(n_rays >= 0 && n_grids >= 1 && n_grids <= kMaxGrids && res >= 1 && res <= 1024, "render_image_test: bad sizes");
     CED_REQUIRE(n_rays < (1ll << 31) / 4, "render_image_test: too many rays for 32-bit sample indices");
     CED_REQUIRE(max_samples >= 0, "render_image_test: max_samples < 0");
     if (total_samples_out) *total_samples_out = 0;
@@ -324,7 +359,7 @@ extern "C" int ced_render_image_test(const ced_field_desc *field, int64_t n_rays
                 "render_image_test: null pointer");
     const int min_samples = min_samples_of(cone_angle);
     const int64_t cap = n_rays * min_samples;
-    FrameWorkspace W = carve(workspace, n_rays, n_grids, cap, max_samples + 1);
+    FrameWorkspace W = carve(workspace, n_rays, n_grids, cap, max_samples + 1, res);
     CED_REQUIRE((int64_t)W.bytes <= workspace_bytes, "render_image_test: workspace too small (%lld < %lld bytes)",
                 (long long)workspace_bytes, (long long)W.bytes);
     const dim3 blk(256), grd((unsigned)((n_rays + 255) / 256));
@@ -341,6 +376,12 @@ extern "C" int ced_render_image_test(const ced_field_desc *field, int64_t n_rays
                        W.t_sorted, W.t_indices, W.hits, W.near, W.mask, rgb, opacity, depth);
     if (hipMemsetAsync(W.counters, 0, (size_t)(max_samples + 2) * 8, stream) != hipSuccess)
         return check_launch("render_image_test (memset)");
+    const int nb = (res + kBrick - 1) / kBrick;
+    const int n_bricks = n_grids * nb * nb * nb;
+    hipLaunchKernelGGL(brick_any_kernel, dim3(n_bricks), dim3(64), 0, stream, binaries, (int)n_grids, (int)res, nb,
+                       W.brick_any);
+    hipLaunchKernelGGL(brick_dilate_kernel, dim3((n_bricks + 255) / 256), blk, 0, stream, W.brick_any, (int)n_grids, nb,
+                       W.brick_dil);
     int rc = check_launch("render_image_test (prep)");
     if (rc) return rc;
 
@@ -355,7 +396,8 @@ extern "C" int ced_render_image_test(const ced_field_desc *field, int64_t n_rays
         unsigned long long *counter = W.counters + it;
 
         MarchArgs M{ n_rays, rays_o, rays_d,
-                     GridSpec{ binaries, aabbs, n_grids, res, step_size, cone_angle, n_samples },
+                     GridSpec{ binaries, aabbs, n_grids, res, step_size, cone_angle, n_samples,
+                               g_march_early_out ? W.brick_dil : nullptr, nb },
                      W.near, far_plane, W.mask, W.t_sorted, W.t_indices, W.hits, W.t0, W.t1, W.ridx, W.packed, counter };
         // as many rays per workgroup as 128 KB of sample staging allow: fewer, larger reservations
         const int threads = n_samples <= 16 ? 1024 : (n_samples <= 32 ? 512 : 256);

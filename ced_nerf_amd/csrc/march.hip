@@ -138,7 +138,7 @@ extern "C" int ced_traverse_grids(int64_t n_rays, const float *rays_o, const flo
     if (mode == 1 || mode == 3)
         CED_REQUIRE(base && t_starts && t_ends, "traverse_grids: fill mode needs base/t_starts/t_ends");
     if (mode == 2) CED_REQUIRE(limit > 0 && t_starts && t_ends, "traverse_grids: over-allocate needs limit > 0");
-    ced::TraverseArgs A{ n_rays, rays_o, rays_d, ced::GridSpec{ binaries, aabbs, n_grids, res, step_size, cone_angle, limit },
+    ced::TraverseArgs A{ n_rays, rays_o, rays_d, ced::GridSpec{ binaries, aabbs, n_grids, res, step_size, cone_angle, limit, nullptr, 0 },
                          near_planes, far_planes, rays_mask, t_sorted, t_indices, hits, mode, base, counts, t_starts,
                          t_ends, ray_indices, termination_planes, packed_info_out };
     dim3 block(256), grid((unsigned)((n_rays + 255) / 256));

@@ -91,7 +91,14 @@ struct GridSpec {
     int n_grids, res;
     float step_size, cone_angle;
     int limit;                 // <= 0: unlimited
+    // Optional conservative early-out (frame renderer only): dilated brick occupancy
+    // [n_grids, nb, nb, nb] bytes, nb = ceil(res / kBrick); brick b is set when any cell of the
+    // 3x3x3 bricks around b is occupied.  NULL disables it.
+    const uint8_t *dilated_bricks;
+    int nb;
 };
+
+constexpr int kBrick = 8;      // cells per brick side
 
 #ifndef CED_KLOOK
 #define CED_KLOOK 8
@@ -99,6 +106,40 @@ struct GridSpec {
 constexpr int kLook = CED_KLOOK;   // DDA look-ahead (cells whose occupancy bytes are fetched together)
 
 #if defined(__HIPCC__)
+// Conservative emptiness test of the ray segment [t_a, t_b] on grid level `lvl`: true only if no cell
+// the fine DDA can visit there is occupied.  Points are probed every 6 cells (of the smallest cell
+// edge); a cell visited between two probes is < 8 cells (6 + DDA/rounding slop) from the earlier probe
+// on every axis, i.e. inside the 3x3x3 bricks around that probe's brick, which the dilated mask covers.
+__device__ __forceinline__ bool segment_clear(const GridSpec &G, int lvl, const float (&o)[3], const float (&d)[3],
+                                              float t_a, float t_b)
+{
+    const float *ab = G.aabbs + 6 * lvl;
+    const float resf = (float)G.res;
+    float inv_ext[3], vmin = 3.4e38f;
+#pragma unroll
+    for (int a = 0; a < 3; ++a) {
+        const float ext = ab[3 + a] - ab[a];
+        inv_ext[a] = resf / ext;
+        vmin = fminf(vmin, ext / resf);
+    }
+    const float dn = sqrtf(d[0] * d[0] + d[1] * d[1] + d[2] * d[2]);
+    const float dt = 6.0f * vmin / fmaxf(dn, 1e-20f);
+    const uint8_t *mask = G.dilated_bricks + (size_t)lvl * G.nb * G.nb * G.nb;
+    if (!(dt > 0.0f) || !(t_b - t_a < 4096.0f * dt)) return false;      // degenerate / absurdly long: do not claim
+    for (float t = t_a;; t += dt) {
+        const float tc = fminf(t, t_b);
+        int b[3];
+#pragma unroll
+        for (int a = 0; a < 3; ++a) {
+            const int c = clampi((int)((o[a] + d[a] * tc - ab[a]) * inv_ext[a]), 0, G.res - 1);
+            b[a] = c / kBrick;
+        }
+        if (mask[(b[0] * G.nb + b[1]) * G.nb + b[2]]) return false;
+        if (t >= t_b) break;
+    }
+    return true;
+}
+
 // Traverses one ray; calls emit(i, t_start, t_end) for sample i = 0.. in order.  Returns the
 // number of samples; t_term receives the termination plane.
 template <class Emit>
@@ -116,6 +157,9 @@ __device__ __forceinline__ int traverse_ray(const GridSpec &G, const float (&o)[
     bool continuous = false;
     int n = 0;
     for (int i = 0; i < 2 * n_grids - 1; ++i) {
+        // Sample budget used up: later segments change nothing (the cell loop would not run and
+        // `continuous` is true right after an emission), so stop before any early-out can touch state.
+        if (limit > 0 && n >= limit) break;
         int64_t ti = ti_row[i];
         bool entering = ti < n_grids;
         int lvl = (int)(ti % n_grids);
@@ -151,6 +195,13 @@ __device__ __forceinline__ int traverse_ray(const GridSpec &G, const float (&o)[
             ovf[a] = fin + stp[a];
         }
         const uint8_t *grid = G.binaries + (int64_t)lvl * res * res * res;
+        // Early-out (frame renderer): when the rest of this segment provably holds no occupied cell,
+        // walking it cell by cell would emit nothing.  Skipping it leaves t_last on an earlier point of
+        // the same step lattice, so any later sample is unchanged; only the termination plane of a ray
+        // that ends the call short of `limit` -- a ray that is dead afterwards -- is not advanced.
+        const bool can_skip = G.dilated_bricks != nullptr;
+        if (can_skip && segment_clear(G, lvl, o, d, this_tmin, this_tmax)) { continuous = false; continue; }
+        int empty_batches = 0;
         // The DDA path does not depend on the occupancy values, so it runs kLook cells ahead and the
         // occupancy bytes of those cells are fetched together.  Runs of empty cells only remember
         // the farthest boundary; the skip-march to it happens once, before the next occupied cell or
@@ -220,6 +271,12 @@ __device__ __forceinline__ int traverse_ray(const GridSpec &G, const float (&o)[
                     t_last = t_next;
                     if (t_next >= t_trav) break;
                 }
+            }
+            if (can_skip && has_pending && !dda_done && !stop) {
+                // in empty space: every 4th all-empty stretch, ask whether anything is left ahead
+                if ((empty_batches++ & 3) == 0 && segment_clear(G, lvl, o, d, pending, this_tmax)) dda_done = true;
+            } else {
+                empty_batches = 0;
             }
         }
         if (has_pending) t_last = skip_march(t_last, pending, step_size, cone_angle);

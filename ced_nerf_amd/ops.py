@@ -318,7 +318,7 @@ def render_image_test_native(desc: _lib.FieldDesc, rays_o, rays_d, binaries, aab
         assert timestamps.numel() == n, "per-ray timestamps must have one entry per ray"
     dev = rays_o.device
     L = _lib.lib()
-    need = int(L.ced_render_image_test_workspace_bytes(n, m, float(cone_angle), int(max_samples)))
+    need = int(L.ced_render_image_test_workspace_bytes(n, m, res, float(cone_angle), int(max_samples)))
     if need < 0:
         raise ValueError("render_image_test: unsupported sizes")
     key = (dev.index, torch.cuda.current_stream().cuda_stream)

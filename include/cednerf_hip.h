@@ -73,7 +73,9 @@ int ced_version(void);
 const char *ced_last_error_string(void);
 
 /* Tuning knobs (process-wide).  "field_variant": launch geometry of the fused field kernel,
- * 0 = 4 column tiles x 512 threads, 1 = 2 x 512, 2 = 2 x 768, 3 = 2 x 1024 (results are identical). */
+ * 0 = 4 column tiles x 512 threads, 1 = 2 x 512, 2 = 2 x 768 (default), 3 = 2 x 1024;
+ * "march_early_out": 1 (default) lets ced_render_image_test stop walking a ray once a dilated
+ * brick mask proves nothing occupied lies ahead, 0 walks every cell.  Results are identical. */
 int ced_set_option(const char *key, int value);
 
 /* Number of floats in the packed (MFMA-fragment-order) weight blob. */
@@ -209,7 +211,7 @@ typedef struct ced_frame_trace {
 } ced_frame_trace;
 
 /* Device bytes ced_render_image_test needs in `workspace` (negative on bad arguments). */
-int64_t ced_render_image_test_workspace_bytes(int64_t n_rays, int32_t n_grids, float cone_angle,
+int64_t ced_render_image_test_workspace_bytes(int64_t n_rays, int32_t n_grids, int32_t res, float cone_angle,
                                               int32_t max_samples);
 
 /* render_image_test(max_samples, radiance_field, estimator, rays, near_plane, far_plane,

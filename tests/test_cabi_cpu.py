@@ -43,8 +43,8 @@ def test_argument_errors_are_reported_not_thrown():
     d.hash.n_levels = 12
     assert L.ced_field_forward(C.byref(d), 4, 1, 1, None, None, 1, None, None) != 0
     assert L.ced_field_forward(C.byref(d), 0, None, None, None, None, None, None, None) == 0            # n == 0
-    assert L.ced_render_image_test_workspace_bytes(640000, 1, 0.0, 1024) > 0
-    assert L.ced_render_image_test_workspace_bytes(10, 9, 0.0, 16) < 0                                  # too many grids
+    assert L.ced_render_image_test_workspace_bytes(640000, 1, 128, 0.0, 1024) > 0
+    assert L.ced_render_image_test_workspace_bytes(10, 9, 128, 0.0, 16) < 0                                  # too many grids
     tot = C.c_int64(-1)
     assert L.ced_render_image_test(C.byref(d), 0, None, None, None, 1, 128, None, 0.0, 1e10, 5e-3, 0.0, 1e-4, 64, None, 0,
                                    None, None, None, None, None, 0, None, C.byref(tot), None, None) == 0   # no rays
