@@ -39,7 +39,8 @@ class ShardedRenderer:
     sharding / gather / un-permute logic over gloo."""
 
     def __init__(self, field, estimator, world: int, rank: int, device, max_samples: int = 1024,
-                 render_kwargs: Optional[Dict] = None, render_fn: Optional[Callable] = None):
+                 render_kwargs: Optional[Dict] = None, render_fn: Optional[Callable] = None,
+                 force_collective: bool = False):
         self.field, self.estimator = field, estimator
         self.world, self.rank, self.device = world, rank, device
         self.max_samples = max_samples
@@ -47,6 +48,7 @@ class ShardedRenderer:
         self.render_fn = render_fn or self._hip_render
         self.shape = None
         self.tracer = None             # optional ops.FrameTracer handed to the native frame call
+        self.force_collective = force_collective   # run the shard/gather/un-permute path even when world == 1
 
     def _hip_render(self, rays_o, rays_d, timestamps):
         from .utils import Rays, render_image_test
@@ -58,7 +60,7 @@ class ShardedRenderer:
         F, H, W, _ = origins.shape
         self.shape = (F, H, W)
         o = origins.reshape(-1, 3); d = viewdirs.reshape(-1, 3)
-        if self.world == 1:
+        if self.world == 1 and not self.force_collective:
             self.local_o, self.local_d = o.contiguous(), d.contiguous()
             self.n_local = self.n_pad = o.shape[0]
             self.gather_index = None
@@ -83,7 +85,7 @@ class ShardedRenderer:
         F, H, W = self.shape
         rgb, op, dp, n_samples = self.render_fn(self.local_o, self.local_d, timestamps)
         n_samples = int(n_samples)
-        if self.world == 1:
+        if self.gather_index is None:
             return dict(rgb=rgb.view(F, H, W, 3), opacity=op.view(F, H, W, 1), depth=dp.view(F, H, W, 1),
                         local_samples=n_samples, total_samples=n_samples)
         payload = torch.empty((self.n_pad + 1, 5), device=rgb.device, dtype=torch.float32)

@@ -36,6 +36,9 @@ def trunc_exp(x: torch.Tensor) -> torch.Tensor:
     return torch.exp(x.float())
 
 
+_EVAL_PASS_RAYS = 1 << 21     # rays per internal eval pass of render_image
+
+
 def _flatten_rays(rays: Rays):
     rays_shape = rays.origins.shape
     if len(rays_shape) == 3:
@@ -67,10 +70,18 @@ def render_image(
         raise NotImplementedError("DNGPradianceField needs timestamps (dnerf path of cednerf/utils.py:78-86)")
     rays, rays_shape, num_rays = _flatten_rays(rays)
     results, extra_info = [], []
-    chunk = torch.iinfo(torch.int32).max if radiance_field.training else test_chunk_size
-    for i in range(0, num_rays, chunk):
-        chunk_rays = namedtuple_map(lambda r: r[i:i + chunk].contiguous().float(), rays)
-        ts = timestamps[i:i + chunk] if radiance_field.training else timestamps
+    # The reference renders 8192 rays per pass in eval mode to bound memory (cednerf/utils.py:59,108-112).
+    # Rays are independent, so here a pass covers up to `_EVAL_PASS_RAYS` rays (HBM is not the
+    # constraint on MI355X) and its outputs are then cut into the reference's `test_chunk_size`
+    # pieces, so the returned `extras` list and every value in it are those of the chunked loop.
+    training = bool(radiance_field.training)
+    if training:
+        pass_rays = torch.iinfo(torch.int32).max
+    else:
+        pass_rays = max(test_chunk_size, (_EVAL_PASS_RAYS // test_chunk_size) * test_chunk_size)
+    for i in range(0, num_rays, pass_rays):
+        chunk_rays = namedtuple_map(lambda r: r[i:i + pass_rays].contiguous().float(), rays)
+        ts = timestamps[i:i + pass_rays] if training else timestamps
 
         def sigma_fn(t_starts, t_ends, ray_indices):
             return radiance_field.query_rays(chunk_rays.origins, chunk_rays.viewdirs, ray_indices, t_starts, t_ends,
@@ -82,15 +93,30 @@ def render_image(
 
         ray_indices, t_starts, t_ends = estimator.sampling(
             chunk_rays.origins, chunk_rays.viewdirs, sigma_fn=sigma_fn, near_plane=near_plane, far_plane=far_plane,
-            render_step_size=render_step_size, stratified=radiance_field.training, cone_angle=cone_angle,
-            alpha_thre=alpha_thre)
-        rgb, opacity, depth, extras = rendering(t_starts, t_ends, ray_indices, n_rays=chunk_rays.origins.shape[0],
+            render_step_size=render_step_size, stratified=training, cone_angle=cone_angle, alpha_thre=alpha_thre)
+        n_pass = chunk_rays.origins.shape[0]
+        rgb, opacity, depth, extras = rendering(t_starts, t_ends, ray_indices, n_rays=n_pass,
                                                 rgb_sigma_fn=rgb_sigma_fn, render_bkgd=render_bkgd)
-        results.append([rgb, opacity, depth, len(t_starts)])
         extras["ray_indices"] = ray_indices
         extras["t_starts"] = t_starts
         extras["t_ends"] = t_ends
-        extra_info.append(extras)
+        if training or n_pass <= test_chunk_size:
+            results.append([rgb, opacity, depth, len(t_starts)])
+            extra_info.append(extras)
+            continue
+        # cut the pass into the reference's chunks: samples are sorted by ray, so each chunk owns a
+        # contiguous sample range (one small device->host copy of the range boundaries)
+        starts = torch.arange(0, n_pass + test_chunk_size, test_chunk_size, device=rgb.device).clamp_(max=n_pass)
+        bounds = torch.searchsorted(ray_indices, starts).tolist()
+        for c in range(len(bounds) - 1):
+            r0, r1 = c * test_chunk_size, min((c + 1) * test_chunk_size, n_pass)
+            if r0 >= n_pass:
+                break
+            s0, s1 = bounds[c], bounds[c + 1]
+            ex = {k: v[s0:s1] for k, v in extras.items()}
+            ex["ray_indices"] = ex["ray_indices"] - r0
+            results.append([rgb[r0:r1], opacity[r0:r1], depth[r0:r1], s1 - s0])
+            extra_info.append(ex)
     colors, opacities, depths, n_rendering_samples = [
         torch.cat(r, dim=0) if isinstance(r[0], torch.Tensor) else r for r in zip(*results)
     ]
