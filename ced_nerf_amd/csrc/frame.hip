@@ -52,7 +52,7 @@ __global__ __launch_bounds__(256) void frame_prep_kernel(int64_t n_rays, const f
                                                          const float *__restrict__ aabbs, float near_plane,
                                                          float *__restrict__ t_sorted, int64_t *__restrict__ t_indices,
                                                          uint8_t *__restrict__ hits, float *__restrict__ near_planes,
-                                                         uint8_t *__restrict__ ray_mask, float *__restrict__ rgb,
+                                                         float *__restrict__ rgb,
                                                          float *__restrict__ opacity, float *__restrict__ depth)
 {
     int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -82,7 +82,6 @@ __global__ __launch_bounds__(256) void frame_prep_kernel(int64_t n_rays, const f
         t_indices[r * 2 * m + i] = id[i];
     }
     near_planes[r] = near_plane;
-    ray_mask[r] = 1;
     rgb[3 * r] = 0.0f; rgb[3 * r + 1] = 0.0f; rgb[3 * r + 2] = 0.0f;
     opacity[r] = 0.0f;
     depth[r] = 0.0f;
@@ -125,7 +124,8 @@ struct MarchArgs {
     GridSpec grid;
     float *near_planes;            // in: near plane, out: termination plane (cednerf/utils.py:301)
     float far_plane;
-    const uint8_t *ray_mask;
+    const int32_t *alive;          // ids of the rays still alive (NULL: all rays, first iteration)
+    int64_t n_alive;
     const float *t_sorted;
     const int64_t *t_indices;
     const uint8_t *hits;
@@ -148,9 +148,11 @@ __global__ void march_alloc_kernel(MarchArgs A)
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, n_waves = blockDim.x >> 6;
     const int limit = A.grid.limit;
     float2 *stage = stage_all + (size_t)wave * limit * 64;
-    const int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int64_t slot = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const bool active = slot < A.n_alive;
+    const int64_t r = active ? (A.alive ? (int64_t)A.alive[slot] : slot) : 0;
     int n = 0;
-    if (r < A.n_rays && A.ray_mask[r]) {
+    if (active) {
         const float o[3] = { A.rays_o[3 * r], A.rays_o[3 * r + 1], A.rays_o[3 * r + 2] };
         const float d[3] = { A.rays_d[3 * r], A.rays_d[3 * r + 1], A.rays_d[3 * r + 2] };
         const int m = A.grid.n_grids;
@@ -176,7 +178,7 @@ __global__ void march_alloc_kernel(MarchArgs A)
     }
     __syncthreads();
     const int64_t start = (int64_t)block_base + wave_tot[wave] + (incl - n);
-    if (r < A.n_rays) {
+    if (active) {
         A.packed[2 * r] = (int32_t)start;
         A.packed[2 * r + 1] = n;
     }
@@ -188,22 +190,28 @@ __global__ void march_alloc_kernel(MarchArgs A)
     }
 }
 
-// composite_prefix (cednerf/utils.py:274-299) + ray bookkeeping (utils.py:301-307), 32-bit packed_info
-__global__ __launch_bounds__(256) void frame_composite_kernel(int64_t n_rays, const int32_t *__restrict__ packed,
+// composite_prefix (cednerf/utils.py:274-299) + ray bookkeeping (utils.py:301-307) over the list of
+// alive rays; survivors (opacity <= threshold and a full sample budget) are appended to the next
+// iteration's list, one range reservation per workgroup.
+__global__ __launch_bounds__(256) void frame_composite_kernel(int64_t n_alive, const int32_t *__restrict__ alive_list,
+                                                              int32_t *__restrict__ next_list,
+                                                              unsigned long long *__restrict__ next_count,
+                                                              const int32_t *__restrict__ packed,
                                                               const float *__restrict__ t0,
                                                               const float *__restrict__ t1,
                                                               const float *__restrict__ sig,
                                                               const float *__restrict__ rgbs, float *__restrict__ rgb,
                                                               float *__restrict__ opacity, float *__restrict__ depth,
-                                                              float opc_thres, int n_samples_iter,
-                                                              uint8_t *__restrict__ ray_mask,
-                                                              long long *__restrict__ block_stats)
+                                                              float opc_thres, int n_samples_iter)
 {
-    __shared__ int red[2][4];
-    int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    __shared__ int wave_alive[4];
+    __shared__ long long block_base;
+    const int64_t slot = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const bool active = slot < n_alive;
+    const int64_t r = active ? (alive_list ? (int64_t)alive_list[slot] : slot) : 0;
     int cnt = 0;
     bool alive = false;
-    if (r < n_rays && ray_mask[r]) {
+    if (active) {
         const int s0 = packed[2 * r];
         cnt = packed[2 * r + 1];
         float op = opacity[r];
@@ -255,20 +263,20 @@ __global__ __launch_bounds__(256) void frame_composite_kernel(int64_t n_rays, co
             depth[r] = dp;
         }
         alive = (op <= opc_thres) && (cnt == n_samples_iter);
-        ray_mask[r] = alive ? 1 : 0;
     }
-    // (alive rays, samples) of this workgroup -> block_stats[blockIdx]; the host adds the partials up
-    // (no atomics: thousands of returning atomics on one word would serialise)
     const unsigned long long ballot = __ballot(alive);
-    int c = cnt;
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) c += __shfl_down(c, off, 64);
-    const int wave = threadIdx.x >> 6;
-    if ((threadIdx.x & 63) == 0) { red[0][wave] = __builtin_popcountll(ballot); red[1][wave] = c; }
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    if (lane == 0) wave_alive[wave] = __builtin_popcountll(ballot);
     __syncthreads();
     if (threadIdx.x == 0) {
-        block_stats[2 * blockIdx.x] = red[0][0] + red[0][1] + red[0][2] + red[0][3];
-        block_stats[2 * blockIdx.x + 1] = red[1][0] + red[1][1] + red[1][2] + red[1][3];
+        int run = 0;
+        for (int w = 0; w < 4; ++w) { int t = wave_alive[w]; wave_alive[w] = run; run += t; }
+        block_base = run > 0 ? (long long)atomicAdd(next_count, (unsigned long long)run) : 0;
+    }
+    __syncthreads();
+    if (alive) {
+        const int rank = __builtin_popcountll(ballot & ((1ull << lane) - 1ull));
+        next_list[block_base + wave_alive[wave] + rank] = (int32_t)r;
     }
 }
 
@@ -291,9 +299,9 @@ __global__ __launch_bounds__(256) void frame_finalize_kernel(int64_t n_rays, con
 static inline size_t align_up(size_t x) { return (x + 255) & ~(size_t)255; }
 
 struct FrameWorkspace {
-    float *t_sorted; int64_t *t_indices; uint8_t *hits; float *near; uint8_t *mask; int32_t *packed;
-    unsigned long long *counters;   // [iters+1] samples reserved by the marching kernel of each iteration
-    long long *block_stats;         // [ceil(n/256)][2] (alive, samples) partials of the compositing kernel
+    float *t_sorted; int64_t *t_indices; uint8_t *hits; float *near; int32_t *packed;
+    int32_t *alive_a, *alive_b;     // double-buffered list of alive ray ids
+    unsigned long long *counters;   // [iters+2][2]: {samples reserved in iteration i, rays alive entering iteration i}
     float *t0, *t1; int32_t *ridx; float *sigma, *rgbs;
     uint8_t *brick_any, *brick_dil;
     size_t bytes;
@@ -308,10 +316,10 @@ static FrameWorkspace carve(void *base, int64_t n, int m, int64_t cap, int max_i
     w.t_indices = (int64_t *)take((size_t)n * 2 * m * 8);
     w.hits = (uint8_t *)take((size_t)n * m);
     w.near = (float *)take((size_t)n * 4);
-    w.mask = (uint8_t *)take((size_t)n);
     w.packed = (int32_t *)take((size_t)n * 8);
-    w.counters = (unsigned long long *)take((size_t)(max_iters + 1) * 8);
-    w.block_stats = (long long *)take((size_t)((n + 255) / 256) * 16);
+    w.alive_a = (int32_t *)take((size_t)n * 4);
+    w.alive_b = (int32_t *)take((size_t)n * 4);
+    w.counters = (unsigned long long *)take((size_t)(max_iters + 2) * 16);
     w.t0 = (float *)take((size_t)cap * 4);
     w.t1 = (float *)take((size_t)cap * 4);
     w.ridx = (int32_t *)take((size_t)cap * 4);
@@ -363,7 +371,6 @@ extern "C" int ced_render_image_test(const ced_field_desc *field, int64_t n_rays
     CED_REQUIRE((int64_t)W.bytes <= workspace_bytes, "render_image_test: workspace too small (%lld < %lld bytes)",
                 (long long)workspace_bytes, (long long)W.bytes);
     const dim3 blk(256), grd((unsigned)((n_rays + 255) / 256));
-    const int64_t n_blocks = (n_rays + 255) / 256;
     static bool lds_attr_set = false;
     if (!lds_attr_set) {        // the marching kernel stages up to 128 KB of samples per workgroup
         if (hipFuncSetAttribute(reinterpret_cast<const void *>(march_alloc_kernel),
@@ -373,8 +380,8 @@ extern "C" int ced_render_image_test(const ced_field_desc *field, int64_t n_rays
     }
 
     hipLaunchKernelGGL(frame_prep_kernel, grd, blk, 0, stream, n_rays, rays_o, rays_d, (int)n_grids, aabbs, near_plane,
-                       W.t_sorted, W.t_indices, W.hits, W.near, W.mask, rgb, opacity, depth);
-    if (hipMemsetAsync(W.counters, 0, (size_t)(max_samples + 2) * 8, stream) != hipSuccess)
+                       W.t_sorted, W.t_indices, W.hits, W.near, rgb, opacity, depth);
+    if (hipMemsetAsync(W.counters, 0, (size_t)(max_samples + 3) * 16, stream) != hipSuccess)
         return check_launch("render_image_test (memset)");
     const int nb = (res + kBrick - 1) / kBrick;
     const int n_bricks = n_grids * nb * nb * nb;
@@ -393,15 +400,20 @@ extern "C" int ced_render_image_test(const ced_field_desc *field, int64_t n_rays
         int n_samples = (int)(q < 64 ? q : 64);
         if (n_samples < min_samples) n_samples = min_samples;
         iter_samples += n_samples;
-        unsigned long long *counter = W.counters + it;
+        unsigned long long *counter = W.counters + (size_t)it * 2;          // samples reserved in this iteration
+        unsigned long long *next_alive = W.counters + (size_t)(it + 1) * 2 + 1;   // rays alive entering the next one
+        const int32_t *cur_list = it == 0 ? nullptr : ((it & 1) ? W.alive_a : W.alive_b);
+        int32_t *next_list = (it & 1) ? W.alive_b : W.alive_a;
 
         MarchArgs M{ n_rays, rays_o, rays_d,
                      GridSpec{ binaries, aabbs, n_grids, res, step_size, cone_angle, n_samples,
                                g_march_early_out ? W.brick_dil : nullptr, nb },
-                     W.near, far_plane, W.mask, W.t_sorted, W.t_indices, W.hits, W.t0, W.t1, W.ridx, W.packed, counter };
-        // as many rays per workgroup as 128 KB of sample staging allow: fewer, larger reservations
-        const int threads = n_samples <= 16 ? 1024 : (n_samples <= 32 ? 512 : 256);
-        hipLaunchKernelGGL(march_alloc_kernel, dim3((unsigned)((n_rays + threads - 1) / threads)), dim3(threads),
+                     W.near, far_plane, cur_list, n_alive, W.t_sorted, W.t_indices, W.hits, W.t0, W.t1, W.ridx, W.packed,
+                     counter };
+        // only alive rays get a lane; 256 rays per workgroup keep the resident-wave granularity fine
+        // (a workgroup lives as long as its slowest ray) while one range reservation serves 256 rays
+        const int threads = 256;
+        hipLaunchKernelGGL(march_alloc_kernel, dim3((unsigned)((n_alive + threads - 1) / threads)), dim3(threads),
                            (size_t)threads * n_samples * sizeof(float2), stream, M);
         rc = check_launch("render_image_test (march)");
         if (rc) return rc;
@@ -413,20 +425,23 @@ extern "C" int ced_render_image_test(const ced_field_desc *field, int64_t n_rays
         F.t0 = W.t0; F.t1 = W.t1; F.timestamps = timestamps;
         F.rays_mode = 1; F.t_per_ray = t_per_ray ? 1 : 0; F.want_rgb = 1;
         F.rgb = W.rgbs; F.sigma = W.sigma; F.geo = nullptr;
-        if (trace && it < trace->capacity && trace->field_begin) hipEventRecord((hipEvent_t)trace->field_begin[it], stream);
+        if (trace && it < trace->capacity && trace->field_begin)
+            (void)hipEventRecord((hipEvent_t)trace->field_begin[it], stream);
         rc = launch_field(field, F, stream_);
         if (rc) return rc;
-        if (trace && it < trace->capacity && trace->field_end) hipEventRecord((hipEvent_t)trace->field_end[it], stream);
+        if (trace && it < trace->capacity && trace->field_end)
+            (void)hipEventRecord((hipEvent_t)trace->field_end[it], stream);
 
-        hipLaunchKernelGGL(frame_composite_kernel, grd, blk, 0, stream, n_rays, W.packed, W.t0, W.t1, W.sigma, W.rgbs, rgb,
-                           opacity, depth, opc_thres, n_samples, W.mask, W.block_stats);
+        hipLaunchKernelGGL(frame_composite_kernel, dim3((unsigned)((n_alive + 255) / 256)), blk, 0, stream, n_alive,
+                           cur_list, next_list, next_alive, W.packed, W.t0, W.t1, W.sigma, W.rgbs, rgb, opacity, depth,
+                           opc_thres, n_samples);
         rc = check_launch("render_image_test (composite)");
         if (rc) return rc;
-        if (hipMemcpyAsync(host_stats, W.block_stats, (size_t)n_blocks * 16, hipMemcpyDeviceToHost, stream) != hipSuccess ||
+        // {samples of this iteration, rays alive for the next}: 3 adjacent counters, one copy, one sync
+        if (hipMemcpyAsync(host_stats, counter, 32, hipMemcpyDeviceToHost, stream) != hipSuccess ||
             hipStreamSynchronize(stream) != hipSuccess)
             return check_launch("render_image_test (stats copy)");
-        int64_t alive_next = 0, samples_it = 0;
-        for (int64_t b = 0; b < n_blocks; ++b) { alive_next += host_stats[2 * b]; samples_it += host_stats[2 * b + 1]; }
+        const int64_t samples_it = host_stats[0], alive_next = host_stats[3];
         if (trace && it < trace->capacity) {
             if (trace->iter_alive) trace->iter_alive[it] = n_alive;
             if (trace->iter_n_samples) trace->iter_n_samples[it] = n_samples;

@@ -225,7 +225,7 @@ int64_t ced_render_image_test_workspace_bytes(int64_t n_rays, int32_t n_grids, i
  *   timestamps: device [1] (t_per_ray = 0, eval) or [n_rays] (t_per_ray = 1); bkgd: device [3] or NULL;
  *   outputs rgb [n_rays,3], opacity [n_rays], depth [n_rays] (overwritten);
  *   workspace: device scratch of ced_render_image_test_workspace_bytes() bytes;
- *   host_stats: PINNED host memory, >= 16 * ceil(n_rays / 256) bytes (per-iteration counters land here);
+ *   host_stats: PINNED host memory, >= 32 bytes (per-iteration counters land here);
  *   total_samples_out: host, receives the number of field evaluations (utils.py:307,317).
  * Unlike the other entry points this one BLOCKS: like the reference loop (utils.py:231) it reads
  * the alive-ray count back once per iteration. */
