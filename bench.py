@@ -33,7 +33,10 @@ def parse():
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--width", type=int, default=800)
     ap.add_argument("--height", type=int, default=800)
-    ap.add_argument("--scene", default="dnerf")
+    ap.add_argument("--scene", default="dnerf", choices=["dnerf", "hypernerf", "dynerf"])
+    ap.add_argument("--table-dtype", default="f32", choices=["f32", "f16"])
+    ap.add_argument("--pmc-json", default=os.path.join(ROOT, "profiles", "r01_pmc_field.json"),
+                    help="per-launch HBM traffic of the field kernel from the rocprofv3 --pmc passes (tools/pmc_summary.py)")
     ap.add_argument("--regime", default="trained")
     ap.add_argument("--max-samples", type=int, default=1024)
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -85,8 +88,9 @@ def main():
 
     T = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)
     # one frame per GPU per step: consecutive azimuths of a turntable video
-    frames = [S.make_scene(args.scene, args.width, args.height, args.regime, azim_deg=30.0 + 12.0 * f)
-              for f in range(world)] if world > 1 else [S.make_scene(args.scene, args.width, args.height, args.regime)]
+    tdt = np.float16 if args.table_dtype == "f16" else np.float32
+    frames = [S.make_scene(args.scene, args.width, args.height, args.regime, azim_deg=30.0 + 12.0 * f, table_dtype=tdt)
+              for f in range(world)]
     sc = frames[0]
     cfg = sc["cfg"]
     field = DNGPradianceField.from_params(sc["params"], dev).eval()
@@ -159,14 +163,22 @@ def main():
         samples_per_launch = fk["units"] / fk["launches"]
         tflops = samples_per_launch * ALG_FLOPS_PER_SAMPLE / (avg_ms * 1e-3) / 1e12
         gbs = samples_per_launch * (ALG_BYTES_PER_SAMPLE_F16 if fp16 else ALG_BYTES_PER_SAMPLE_F32) / (avg_ms * 1e-3) / 1e9
+        traffic = None
+        if args.scene == "dnerf" and not fp16 and os.path.exists(args.pmc_json):
+            try:        # HBM bytes per launch from the committed PMC passes of this same workload
+                pj = json.load(open(args.pmc_json))
+                k = [v for n, v in pj.items() if n.startswith("void ced::field_kernel")][0]
+                traffic = k["fetch_bytes_per_launch"] + k["write_bytes_per_launch"]
+            except Exception:
+                traffic = None
         line["roofline"] = {"kernel": "field_kernel (fused DNGPradianceField forward)", "bound": "mfma",
                             "achieved": tflops, "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
-                            "frac": tflops / PEAK_F32_MFMA_TFLOPS, "traffic": None,
+                            "frac": tflops / PEAK_F32_MFMA_TFLOPS, "traffic": traffic,
                             "avg_launch_ms": avg_ms, "launches": fk["launches"],
                             "samples_per_launch": samples_per_launch,
                             "field_share_of_step": fk["ms"] / (1e3 * dt)}
         line["roofline_hbm"] = {"bound": "hbm", "achieved": gbs, "peak": PEAK_HBM_GBS, "unit": "GB/s",
-                                "frac": gbs / PEAK_HBM_GBS, "traffic": None}
+                                "frac": gbs / PEAK_HBM_GBS, "traffic": traffic}
         line["kernel_ms_per_step"] = {k: v["ms"] / args.steps for k, v in prof.items()}
     if not args.no_cpu_baseline:
         line["cpu_baseline"] = cpu_baseline(sc, args)

@@ -12,7 +12,9 @@
 // reference pays at cednerf/utils.py:231.  Sample order in memory differs from nerfacc's (waves
 // reserve ranges in arrival order) but every ray's samples are contiguous and in order, so pixels,
 // sample counts and the schedule are bit-identical.
+#include <atomic>
 #include <cfloat>
+#include <chrono>
 
 #include "ced_common.hpp"
 #include "field_args.hpp"
@@ -296,6 +298,16 @@ __global__ __launch_bounds__(256) void frame_finalize_kernel(int64_t n_rays, con
     depth[r] = depth[r] / __builtin_fmaxf(op, FLT_EPSILON);
 }
 
+// Hands the iteration's two counters to the host through mapped pinned memory and raises a sequence
+// number; the host spins on it instead of paying a copy + hipStreamSynchronize round trip.
+__global__ void frame_publish_kernel(const unsigned long long *__restrict__ counters, long long *host, long long seq)
+{
+    host[0] = (long long)counters[0];       // samples reserved in this iteration
+    host[1] = (long long)counters[3];       // rays alive entering the next iteration
+    __threadfence_system();
+    __hip_atomic_store(&host[2], seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+
 static inline size_t align_up(size_t x) { return (x + 255) & ~(size_t)255; }
 
 struct FrameWorkspace {
@@ -331,6 +343,8 @@ static FrameWorkspace carve(void *base, int64_t n, int m, int64_t cap, int max_i
     w.bytes = off;
     return w;
 }
+
+static std::atomic<long long> g_publish_seq{ 0 };
 
 static inline int min_samples_of(float cone_angle) { return cone_angle == 0.0f ? 1 : 4; }
 
@@ -437,11 +451,25 @@ extern "C" int ced_render_image_test(const ced_field_desc *field, int64_t n_rays
                            opc_thres, n_samples);
         rc = check_launch("render_image_test (composite)");
         if (rc) return rc;
-        // {samples of this iteration, rays alive for the next}: 3 adjacent counters, one copy, one sync
-        if (hipMemcpyAsync(host_stats, counter, 32, hipMemcpyDeviceToHost, stream) != hipSuccess ||
-            hipStreamSynchronize(stream) != hipSuccess)
-            return check_launch("render_image_test (stats copy)");
-        const int64_t samples_it = host_stats[0], alive_next = host_stats[3];
+        // {samples of this iteration, rays alive for the next} -> pinned host memory; spin on the sequence
+        // number (falls back to a stream synchronise if the flag does not show up)
+        const long long seq = ++g_publish_seq;
+        hipLaunchKernelGGL(frame_publish_kernel, dim3(1), dim3(1), 0, stream, counter, (long long *)host_stats, seq);
+        rc = check_launch("render_image_test (publish)");
+        if (rc) return rc;
+        {
+            volatile long long *flag = (volatile long long *)host_stats + 2;
+            const auto t_start = std::chrono::steady_clock::now();
+            long spins = 0;
+            while (__atomic_load_n(flag, __ATOMIC_ACQUIRE) != seq) {
+                if ((++spins & 0xfff) == 0 &&
+                    std::chrono::steady_clock::now() - t_start > std::chrono::milliseconds(200)) {
+                    if (hipStreamSynchronize(stream) != hipSuccess) return check_launch("render_image_test (sync)");
+                    break;
+                }
+            }
+        }
+        const int64_t samples_it = host_stats[0], alive_next = host_stats[1];
         if (trace && it < trace->capacity) {
             if (trace->iter_alive) trace->iter_alive[it] = n_alive;
             if (trace->iter_n_samples) trace->iter_n_samples[it] = n_samples;

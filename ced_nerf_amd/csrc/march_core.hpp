@@ -126,16 +126,26 @@ __device__ __forceinline__ bool segment_clear(const GridSpec &G, int lvl, const 
     const float dt = 6.0f * vmin / fmaxf(dn, 1e-20f);
     const uint8_t *mask = G.dilated_bricks + (size_t)lvl * G.nb * G.nb * G.nb;
     if (!(dt > 0.0f) || !(t_b - t_a < 4096.0f * dt)) return false;      // degenerate / absurdly long: do not claim
-    for (float t = t_a;; t += dt) {
-        const float tc = fminf(t, t_b);
-        int b[3];
+    // probes are independent: fetch kProbe mask bytes per round trip
+    constexpr int kProbe = 4;
+    float t = t_a;
+    for (;;) {
+        uint8_t hit = 0;
 #pragma unroll
-        for (int a = 0; a < 3; ++a) {
-            const int c = clampi((int)((o[a] + d[a] * tc - ab[a]) * inv_ext[a]), 0, G.res - 1);
-            b[a] = c / kBrick;
+        for (int p = 0; p < kProbe; ++p) {
+            const float tc = fminf(t + (float)p * dt, t_b);
+            int b[3];
+#pragma unroll
+            for (int a = 0; a < 3; ++a) {
+                const int c = clampi((int)((o[a] + d[a] * tc - ab[a]) * inv_ext[a]), 0, G.res - 1);
+                b[a] = c / kBrick;
+            }
+            hit |= mask[(b[0] * G.nb + b[1]) * G.nb + b[2]];
         }
-        if (mask[(b[0] * G.nb + b[1]) * G.nb + b[2]]) return false;
-        if (t >= t_b) break;
+        if (hit) return false;
+        t += (float)kProbe * dt;
+        // the last probe of this round sat at min(t - dt, t_b): done once it reached the segment end
+        if (t - dt >= t_b) break;
     }
     return true;
 }
