@@ -103,7 +103,15 @@ __device__ __forceinline__ void to_operand(const f4 (&D)[NT][4], float (&B)[NT][
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
                 float v = D[j][nb][q];
-                r[q] = RELU ? ((v > 0.0f) ? v : 0.0f) : v;
+                if constexpr (RELU) {
+                    // ReLU as ONE integer max on the float's bits: non-negative floats order like their bit
+                    // patterns, every negative float (and -0) has the sign bit set, i.e. a negative int.
+                    // Same result as (v > 0 ? v : 0) for every non-NaN v; the float forms (fmax, compare +
+                    // select, med3) all lower to two v_max_f32, the first one only canonicalising.
+                    const int bits = __float_as_int(v);
+                    v = __int_as_float(bits > 0 ? bits : 0);
+                }
+                r[q] = v;
             }
             transpose4(r[0], r[1], r[2], r[3]);
 #pragma unroll
@@ -112,15 +120,39 @@ __device__ __forceinline__ void to_operand(const f4 (&D)[NT][4], float (&B)[NT][
     }
 }
 
+// Per-level constants, pre-multiplied by the table's bytes per entry (a power of two), so the
+// corner arithmetic below produces byte offsets directly: the xor-hash commutes with the shift
+// ((a^b) << s == (a<<s) ^ (b<<s)) and the dense index is linear.
 struct LevelConst {
     float scale;
-    uint32_t sy, sz;       // per-axis multipliers: primes when hashed, (res, res^2) when dense
-    uint32_t offset, size, hashed;
+    uint32_t sxb, syb, szb;   // per-axis multipliers in bytes: (1, p1, p2) * EB when hashed, (1, res, res^2) * EB when dense
+    uint32_t offb;            // first byte of the level
+    uint32_t sizeb;           // level size in bytes (dense wrap-around)
+    uint32_t maskb;           // (size - 1) * EB (hashed levels: size is a power of two)
+    uint32_t hashed;
 };
 
+template <bool F16, bool TEMPORAL> struct EntryBytes { static constexpr uint32_t value = (F16 ? 4u : 8u) * (TEMPORAL ? 4u : 1u); };
+
+__device__ __forceinline__ LevelConst make_level(float scale, uint32_t res, uint32_t offset, uint32_t size, uint32_t hashed,
+                                                 uint32_t eb)
+{
+    LevelConst L;
+    L.scale = scale;
+    L.sxb = eb;
+    L.syb = (hashed ? 2654435761u : res) * eb;
+    L.szb = (hashed ? 805459861u : res * res) * eb;
+    L.offb = offset * eb;
+    L.sizeb = size * eb;
+    L.maskb = (size - 1u) * eb;
+    L.hashed = hashed;
+    return L;
+}
+
 // Trilinear gather of one level for one point (hash_encoder_half.py:112-161; temporal variant
-// hash_encoder_inter.py:148-197).  x already clamped to [0,1].
-template <bool F16, bool TEMPORAL>
+// hash_encoder_inter.py:148-197).  x already clamped to [0,1].  MODE: 0 = this lane's level may be
+// dense or hashed (both index forms computed, selected per lane), 1 = dense, 2 = hashed.
+template <bool F16, bool TEMPORAL, int MODE>
 __device__ __forceinline__ void hash_level(const LevelConst &L, const void *__restrict__ table, const float (&x)[3],
                                            int k_lo, float t_frac, float &f0, float &f1)
 {
@@ -134,55 +166,66 @@ __device__ __forceinline__ void hash_level(const LevelConst &L, const void *__re
         fr[a] = p - fl;
         om[a] = 1.0f - fr[a];
     }
-    const uint32_t xs[2] = { g[0], g[0] + 1u };
-    const uint32_t ys[2] = { g[1] * L.sy, (g[1] + 1u) * L.sy };
-    const uint32_t zs[2] = { g[2] * L.sz, (g[2] + 1u) * L.sz };
+    const uint32_t xs[2] = { g[0] * L.sxb, g[0] * L.sxb + L.sxb };
+    const uint32_t ys[2] = { g[1] * L.syb, g[1] * L.syb + L.syb };
+    const uint32_t zs[2] = { g[2] * L.szb, g[2] * L.szb + L.szb };
     const bool hashed = L.hashed != 0;
-    const uint32_t mask = L.size - 1u;
-    uint32_t e[8];
+    // y/z combinations are shared by the two x corners
+    uint32_t yz_x[4], yz_a[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        if constexpr (MODE != 1) yz_x[q] = ys[q & 1] ^ zs[q >> 1];
+        if constexpr (MODE != 2) yz_a[q] = ys[q & 1] + zs[q >> 1];
+    }
+    const float wxy[4] = { om[0] * om[1], fr[0] * om[1], om[0] * fr[1], fr[0] * fr[1] };   // index cx + 2*cy
+    uint32_t off[8];
     float w[8];
 #pragma unroll
     for (int c = 0; c < 8; ++c) {
         const int cx = c & 1, cy = (c >> 1) & 1, cz = (c >> 2) & 1;
-        uint32_t hx = xs[cx] ^ ys[cy] ^ zs[cz];
-        uint32_t dx = xs[cx] + ys[cy] + zs[cz];
-        uint32_t dm = (dx >= L.size) ? dx - L.size : dx;
-        e[c] = L.offset + (hashed ? (hx & mask) : dm);
-        float wx = cx ? fr[0] : om[0];
-        float wy = cy ? fr[1] : om[1];
-        float wz = cz ? fr[2] : om[2];
-        w[c] = (wx * wy) * wz;
+        uint32_t hb = 0, db = 0;
+        if constexpr (MODE != 1) hb = (xs[cx] ^ yz_x[cy + 2 * cz]) & L.maskb;
+        if constexpr (MODE != 2) {
+            const uint32_t dx = xs[cx] + yz_a[cy + 2 * cz];
+            db = (dx >= L.sizeb) ? dx - L.sizeb : dx;
+        }
+        const uint32_t idxb = (MODE == 1) ? db : (MODE == 2) ? hb : (hashed ? hb : db);
+        off[c] = L.offb + idxb;
+        w[c] = wxy[cx + 2 * cy] * (cz ? fr[2] : om[2]);
     }
+    const char *tb = reinterpret_cast<const char *>(table);
     float v0[8], v1[8];
     if constexpr (!TEMPORAL) {
         if constexpr (!F16) {
-            const float2 *tb = reinterpret_cast<const float2 *>(table);
-#pragma unroll
-            for (int c = 0; c < 8; ++c) { float2 v = tb[e[c]]; v0[c] = v.x; v1[c] = v.y; }
-        } else {
-            const uint32_t *tb = reinterpret_cast<const uint32_t *>(table);
 #pragma unroll
             for (int c = 0; c < 8; ++c) {
-                uint32_t v = tb[e[c]];
+                const float2 v = *reinterpret_cast<const float2 *>(tb + off[c]);
+                v0[c] = v.x; v1[c] = v.y;
+            }
+        } else {
+#pragma unroll
+            for (int c = 0; c < 8; ++c) {
+                const uint32_t v = *reinterpret_cast<const uint32_t *>(tb + off[c]);
                 v0[c] = half_bits_to_float((uint16_t)(v & 0xffffu));
                 v1[c] = half_bits_to_float((uint16_t)(v >> 16));
             }
         }
     } else {
         const float omt = 1.0f - t_frac;
+        const uint32_t kb = (uint32_t)k_lo * (F16 ? 4u : 8u);      // byte offset of key-frame k_lo inside the entry
         if constexpr (!F16) {
-            const float2 *tb = reinterpret_cast<const float2 *>(table);
 #pragma unroll
             for (int c = 0; c < 8; ++c) {
-                float2 lo = tb[(uint64_t)e[c] * 4u + k_lo], hi = tb[(uint64_t)e[c] * 4u + k_lo + 1];
+                const float2 lo = *reinterpret_cast<const float2 *>(tb + off[c] + kb);
+                const float2 hi = *reinterpret_cast<const float2 *>(tb + off[c] + kb + 8u);
                 v0[c] = lo.x * omt + hi.x * t_frac;
                 v1[c] = lo.y * omt + hi.y * t_frac;
             }
         } else {
-            const uint32_t *tb = reinterpret_cast<const uint32_t *>(table);
 #pragma unroll
             for (int c = 0; c < 8; ++c) {
-                uint32_t lo = tb[(uint64_t)e[c] * 4u + k_lo], hi = tb[(uint64_t)e[c] * 4u + k_lo + 1];
+                const uint32_t lo = *reinterpret_cast<const uint32_t *>(tb + off[c] + kb);
+                const uint32_t hi = *reinterpret_cast<const uint32_t *>(tb + off[c] + kb + 4u);
                 float a0 = half_bits_to_float((uint16_t)(lo & 0xffffu)), a1 = half_bits_to_float((uint16_t)(lo >> 16));
                 float b0 = half_bits_to_float((uint16_t)(hi & 0xffffu)), b1 = half_bits_to_float((uint16_t)(hi >> 16));
                 v0[c] = a0 * omt + b0 * t_frac;
@@ -249,13 +292,16 @@ __global__ __launch_bounds__(THREADS) void field_kernel(FieldArgs A)
         for (int i = tid; i < BL::TOTAL / 4; i += FIELD_THREADS) dst[i] = src[i];
         if (tid < CED_MAX_LEVELS) {
             uint32_t *lt = reinterpret_cast<uint32_t *>(lds + BL::TOTAL);
-            const bool hs = A.hashed[tid] != 0;
-            lt[tid * 8 + 0] = __float_as_uint(A.scale[tid]);
-            lt[tid * 8 + 1] = hs ? 2654435761u : A.res[tid];
-            lt[tid * 8 + 2] = hs ? 805459861u : A.res[tid] * A.res[tid];
-            lt[tid * 8 + 3] = A.offset[tid];
-            lt[tid * 8 + 4] = A.size[tid];
-            lt[tid * 8 + 5] = A.hashed[tid];
+            const LevelConst L = make_level(A.scale[tid], A.res[tid], A.offset[tid], A.size[tid], A.hashed[tid],
+                                            EntryBytes<F16, TEMPORAL>::value);
+            lt[tid * 8 + 0] = __float_as_uint(L.scale);
+            lt[tid * 8 + 1] = L.sxb;
+            lt[tid * 8 + 2] = L.syb;
+            lt[tid * 8 + 3] = L.szb;
+            lt[tid * 8 + 4] = L.offb;
+            lt[tid * 8 + 5] = L.sizeb;
+            lt[tid * 8 + 6] = L.maskb;
+            lt[tid * 8 + 7] = L.hashed;
         }
     }
     __syncthreads();
@@ -267,11 +313,13 @@ __global__ __launch_bounds__(THREADS) void field_kernel(FieldArgs A)
         const int lvl = (i < 2) ? (2 * g + i) : (8 + 2 * g + (i - 2));
         const uint32_t *lt = reinterpret_cast<const uint32_t *>(lds + BL::TOTAL) + lvl * 8;
         LC[i].scale = __uint_as_float(lt[0]);
-        LC[i].sy = lt[1];
-        LC[i].sz = lt[2];
-        LC[i].offset = lt[3];
-        LC[i].size = lt[4];
-        LC[i].hashed = lt[5];
+        LC[i].sxb = lt[1];
+        LC[i].syb = lt[2];
+        LC[i].szb = lt[3];
+        LC[i].offb = lt[4];
+        LC[i].sizeb = lt[5];
+        LC[i].maskb = lt[6];
+        LC[i].hashed = lt[7];
     }
 
     int64_t n_eff = A.n;
@@ -280,6 +328,12 @@ __global__ __launch_bounds__(THREADS) void field_kernel(FieldArgs A)
         n_eff = nd < n_eff ? nd : n_eff;
     }
     const int64_t n_tiles = (n_eff + TILE - 1) / TILE;
+    if (A.stagger > 0) {
+        // Waves w, w+4, w+8 of a workgroup share a SIMD and run the same program: offset their phases so
+        // that their MFMA-dense and VALU-dense stretches interleave instead of colliding.
+        const int slot = __builtin_amdgcn_readfirstlane(wave >> 2);
+        for (int k = 0; k < slot * A.stagger; ++k) __builtin_amdgcn_s_sleep(127);
+    }
     const float extent[3] = { A.aabb[3] - A.aabb[0], A.aabb[4] - A.aabb[1], A.aabb[5] - A.aabb[2] };
 
     for (int64_t tile = (int64_t)blockIdx.x * FIELD_WAVES + wave; tile < n_tiles;
@@ -373,9 +427,15 @@ __global__ __launch_bounds__(THREADS) void field_kernel(FieldArgs A)
             float t_frac = 0.0f;
             if constexpr (TEMPORAL) temporal_keyframe(tq[j], k_lo, t_frac);
             float R[8];
+            // slot i of the four lane groups covers levels {i, 2+i, 4+i, 6+i} (i < 2) or {8.., ..}: when they
+            // are all dense or all hashed (wave-uniform, decided on the host) only that index form is computed
 #pragma unroll
-            for (int i = 0; i < 4; ++i)
-                hash_level<F16, TEMPORAL>(LC[i], A.table, xn[j], k_lo, t_frac, R[2 * i], R[2 * i + 1]);
+            for (int i = 0; i < 4; ++i) {
+                const int mode = (A.level_mode >> (2 * i)) & 3;
+                if (mode == 1) hash_level<F16, TEMPORAL, 1>(LC[i], A.table, xn[j], k_lo, t_frac, R[2 * i], R[2 * i + 1]);
+                else if (mode == 2) hash_level<F16, TEMPORAL, 2>(LC[i], A.table, xn[j], k_lo, t_frac, R[2 * i], R[2 * i + 1]);
+                else hash_level<F16, TEMPORAL, 0>(LC[i], A.table, xn[j], k_lo, t_frac, R[2 * i], R[2 * i + 1]);
+            }
             transpose4(R[0], R[1], R[2], R[3]);
             transpose4(R[4], R[5], R[6], R[7]);
 #pragma unroll
@@ -478,22 +538,18 @@ __global__ __launch_bounds__(256) void hash_encode_kernel(HashArgs A)
 #pragma unroll
     for (int l = 0; l < CED_MAX_LEVELS; ++l) {
         if (l < A.n_levels) {
-            LevelConst L;
-            const bool hs = A.hashed[l] != 0;
-            L.scale = A.scale[l];
-            L.sy = hs ? 2654435761u : A.res[l];
-            L.sz = hs ? 805459861u : A.res[l] * A.res[l];
-            L.offset = A.offset[l];
-            L.size = A.size[l];
-            L.hashed = A.hashed[l];
+            const LevelConst L = make_level(A.scale[l], A.res[l], A.offset[l], A.size[l], A.hashed[l],
+                                            EntryBytes<F16, TEMPORAL>::value);
             float f0, f1;
-            hash_level<F16, TEMPORAL>(L, A.table, x, k_lo, t_frac, f0, f1);
+            if (A.hashed[l]) hash_level<F16, TEMPORAL, 2>(L, A.table, x, k_lo, t_frac, f0, f1);      // level-uniform
+            else hash_level<F16, TEMPORAL, 1>(L, A.table, x, k_lo, t_frac, f0, f1);
             o[2 * l] = f0;
             o[2 * l + 1] = f1;
         }
     }
 }
 
+int g_field_stagger = 0;          // field kernel: start-up phase offset between the waves of a SIMD, in s_sleep(127) units
 bool g_march_early_out = true;    // frame renderer: conservative brick-level early-out (ced_set_option)
 
 // launch-geometry variant of the field kernel (ced_set_option("field_variant", v))
@@ -546,6 +602,17 @@ int launch_field(const ced_field_desc *d, FieldArgs &A, void *stream)
         A.size[l] = d->hash.size[l];
         A.hashed[l] = d->hash.hashed[l];
     }
+    // per slot i: the levels {2g+i | g} (i < 2) / {8+2g+(i-2) | g}: 1 = all dense, 2 = all hashed, 0 = mixed
+    A.level_mode = 0;
+    for (int i = 0; i < 4; ++i) {
+        int n_hashed = 0;
+        for (int g = 0; g < 4; ++g) n_hashed += d->hash.hashed[(i < 2) ? (2 * g + i) : (8 + 2 * g + (i - 2))] ? 1 : 0;
+        A.level_mode |= (n_hashed == 0 ? 1 : (n_hashed == 4 ? 2 : 0)) << (2 * i);
+    }
+    // byte offsets are 32-bit
+    CED_REQUIRE(d->hash.total_entries * (uint64_t)((A.table_dtype ? 4 : 8) * (A.temporal ? 4 : 1)) < (1ull << 32),
+                "field_forward: hash table larger than 4 GiB");
+    A.stagger = g_field_stagger;
     const int variant = g_field_variant;
     auto launch = [&](auto kernel, int nt, int threads) {
         const int64_t n_tiles = (A.n + 16 * nt - 1) / (16 * nt);
@@ -581,6 +648,11 @@ int launch_field(const ced_field_desc *d, FieldArgs &A, void *stream)
 extern "C" int ced_set_option(const char *key, int value)
 {
     CED_REQUIRE(key != nullptr, "set_option: null key");
+    if (strcmp(key, "field_stagger") == 0) {
+        CED_REQUIRE(value >= 0 && value <= 64, "set_option: field_stagger must be 0..64");
+        ced::g_field_stagger = value;
+        return CED_OK;
+    }
     if (strcmp(key, "march_early_out") == 0) {
         ced::g_march_early_out = value != 0;
         return CED_OK;

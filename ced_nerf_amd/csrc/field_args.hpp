@@ -21,6 +21,8 @@ struct FieldArgs {
     int use_div, time_mode;
     const float *weights;
     int table_dtype, temporal;
+    int stagger;                                      // start-up phase offset between SIMD-mates (s_sleep(127) units)
+    int level_mode;                                   // 2 bits per gather slot: 0 mixed, 1 all dense, 2 all hashed
     const void *table;
     float scale[CED_MAX_LEVELS];
     uint32_t res[CED_MAX_LEVELS], offset[CED_MAX_LEVELS], size[CED_MAX_LEVELS], hashed[CED_MAX_LEVELS];

@@ -12,7 +12,9 @@ T = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)
 scene = sys.argv[1] if len(sys.argv) > 1 else "dnerf"
 dtype = np.float16 if (len(sys.argv) > 2 and sys.argv[2] == "f16") else np.float32
 W = H = 800 if scene == "dnerf" else 600
-sc = S.make_scene(scene, W, H, "trained", table_dtype=dtype)
+log2T = int(os.environ.get("LOG2T", "21"))
+sc = S.make_scene(scene, W, H, "trained", table_dtype=dtype, log2_hashmap_size=log2T)
+print("log2T", log2T, "table MB", sc["params"]["hash"]["table"].nbytes / 1e6)
 cfg = sc["cfg"]
 f = DNGPradianceField.from_params(sc["params"], dev).eval()
 o = T(sc["origins"]).reshape(-1, 3); d = T(sc["viewdirs"]).reshape(-1, 3)
@@ -25,17 +27,18 @@ ts = T(sc["timestamps"]).reshape(-1)
 N = t0.shape[0]
 print("samples", N)
 res = {}
-for variant in (0, 1, 2, 3):
+for variant in [int(v) for v in os.environ.get('VARIANTS', '2').split(',')]:
     _lib.check(_lib.lib().ced_set_option(b"field_variant", variant))
-    for want_rgb in (True, False):
-        for _ in range(2):
-            ops.field_forward_rays(f._descriptor(), o, d, ri, t0, t1, ts, False, want_rgb)
-        torch.cuda.synchronize()
-        e0 = torch.cuda.Event(enable_timing=True); e1 = torch.cuda.Event(enable_timing=True)
-        e0.record()
-        for _ in range(5):
-            ops.field_forward_rays(f._descriptor(), o, d, ri, t0, t1, ts, False, want_rgb)
-        e1.record(); torch.cuda.synchronize()
-        ms = e0.elapsed_time(e1) / 5
-        res[(variant, want_rgb)] = ms
-        print(f"variant {variant} rgb={want_rgb}: {ms:.3f} ms  {N/ms/1e6:.1f} Msamples/ms -> {N/ms*1e3/1e9:.3f} Gsamples/s, {N*38e3/ms*1e3/1e12:.1f} TFLOP/s(alg)")
+    for stg in [int(v) for v in os.environ.get('STAGGER', '0').split(',')]:
+        _lib.check(_lib.lib().ced_set_option(b"field_stagger", stg))
+        for want_rgb in (True,):
+            for _ in range(2):
+                ops.field_forward_rays(f._descriptor(), o, d, ri, t0, t1, ts, False, want_rgb)
+            torch.cuda.synchronize()
+            e0 = torch.cuda.Event(enable_timing=True); e1 = torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for _ in range(5):
+                ops.field_forward_rays(f._descriptor(), o, d, ri, t0, t1, ts, False, want_rgb)
+            e1.record(); torch.cuda.synchronize()
+            ms = e0.elapsed_time(e1) / 5
+            print(f"variant {variant} stagger {stg} rgb={want_rgb}: {ms:.3f} ms -> {N/ms*1e3/1e9:.3f} Gsamples/s, {N*38e3/ms*1e3/1e12:.1f} TFLOP/s(alg)")
