@@ -42,6 +42,8 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-stride", type=int, default=1, help="pixel stride of the CPU-baseline ray sample")
     ap.add_argument("--cpu-passes", type=int, default=3, help="how many times the CPU baseline renders its sample")
+    ap.add_argument("--torch-stride", type=int, default=4,
+                    help="pixel stride of the ray sample the PyTorch-fp32 CPU path renders (0 = skip)")
     return ap.parse_args()
 
 
@@ -66,6 +68,27 @@ def cpu_baseline(sc, args):
             "sample": f"{args.cpu_passes} passes over every {s}th pixel in x and y of the same "
                       f"{args.width}x{args.height} frame ({o.shape[0] * o.shape[1]} rays, {out[3]} samples, "
                       f"{dt:.1f} s per pass)"}
+
+
+def cpu_baseline_pytorch(sc, args):
+    """The pure-PyTorch fp32 restatement (oracle/torch_oracle.py: torch field + compositing, native
+    marching as in the reference) on the host cores, on a strided sample of the same frame."""
+    import torch as _t
+    from oracle import oracle as O, torch_oracle as TO
+    cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    _t.set_num_threads(min(cores, 64))
+    cfg = sc["cfg"]
+    tf = TO.TorchField(sc["params"])
+    oest = O.OracleEstimator(cfg["aabb"], cfg["grid_resolution"], cfg["grid_levels"], sc["binaries"])
+    s = args.torch_stride
+    o = np.ascontiguousarray(sc["origins"][::s, ::s]); d = np.ascontiguousarray(sc["viewdirs"][::s, ::s])
+    t0 = time.perf_counter()
+    out = TO.render_image_test(args.max_samples, tf, oest, o, d, timestamps=sc["timestamps"], **sc["render"])
+    dt = time.perf_counter() - t0
+    return {"value": out[3] / dt, "unit": "samples/s", "cores": _t.get_num_threads(), "kind": "port (PyTorch fp32)",
+            "rays_per_sec": o.shape[0] * o.shape[1] / dt,
+            "sample": f"every {s}th pixel in x and y of the same frame ({o.shape[0] * o.shape[1]} rays, {out[3]} samples, "
+                      f"{dt:.1f} s)"}
 
 
 def main():
@@ -185,6 +208,8 @@ def main():
         line["kernel_ms_per_step"] = {k: v["ms"] / args.steps for k, v in prof.items()}
     if not args.no_cpu_baseline:
         line["cpu_baseline"] = cpu_baseline(sc, args)
+        if args.torch_stride > 0:
+            line["cpu_baseline_pytorch"] = cpu_baseline_pytorch(sc, args)
     print(json.dumps(line))
     if world > 1:
         dist.destroy_process_group()

@@ -103,7 +103,11 @@ __device__ __forceinline__ void to_operand(const f4 (&D)[NT][4], float (&B)[NT][
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
                 float v = D[j][nb][q];
+#ifdef CED_FIELD_SKELETON
+                if constexpr (false) {
+#else
                 if constexpr (RELU) {
+#endif
                     // ReLU as ONE integer max on the float's bits: non-negative floats order like their bit
                     // patterns, every negative float (and -0) has the sign bit set, i.e. a negative int.
                     // Same result as (v > 0 ? v : 0) for every non-NaN v; the float forms (fmax, compare +
@@ -113,7 +117,9 @@ __device__ __forceinline__ void to_operand(const f4 (&D)[NT][4], float (&B)[NT][
                 }
                 r[q] = v;
             }
+#ifndef CED_FIELD_SKELETON
             transpose4(r[0], r[1], r[2], r[3]);
+#endif
 #pragma unroll
             for (int s = 0; s < 4; ++s) B[j][4 * nb + s] = r[s];
         }
@@ -335,6 +341,15 @@ __global__ __launch_bounds__(THREADS) void field_kernel(FieldArgs A)
         for (int k = 0; k < slot * A.stagger; ++k) __builtin_amdgcn_s_sleep(127);
     }
     const float extent[3] = { A.aabb[3] - A.aabb[0], A.aabb[4] - A.aabb[1], A.aabb[5] - A.aabb[2] };
+    // In eval frames every sample carries the same timestamp (cednerf/utils.py:186-193): the two
+    // Frequency features of t that this lane feeds to the motion MLP are computed once.
+    const bool shared_time = A.rays_mode && !A.t_per_ray;
+    float t_feat[2] = { 0.0f, 0.0f };
+    if (shared_time) {
+        const float t_all = A.timestamps[0];
+#pragma unroll
+        for (int S = 6; S < 8; ++S) t_feat[S - 6] = det_sinpi_phase(t_all * (float)(1 << (2 * (S & 1) + (g >> 1))), g & 1);
+    }
 
     for (int64_t tile = (int64_t)blockIdx.x * FIELD_WAVES + wave; tile < n_tiles;
          tile += (int64_t)gridDim.x * FIELD_WAVES) {
@@ -376,10 +391,18 @@ __global__ __launch_bounds__(THREADS) void field_kernel(FieldArgs A)
 #pragma unroll
             for (int S = 0; S < 8; ++S) {
                 const int dim = S >> 1;
+                if (dim == 3 && shared_time) {           // eval frames: one timestamp for every sample
+                    B[j][S] = t_feat[S - 6];
+                    continue;
+                }
                 const float v = (dim < 3) ? px[j][dim < 3 ? dim : 0] : tq[j];
                 const int f = 2 * (S & 1) + (g >> 1);
                 const float y = v * (float)(1 << f);
+#ifdef CED_FIELD_SKELETON
+                B[j][S] = y;
+#else
                 B[j][S] = det_sinpi_phase(y, g & 1);
+#endif
             }
         }
         // --- motion MLP 32-64-64-64-(3|6) ---
@@ -427,6 +450,10 @@ __global__ __launch_bounds__(THREADS) void field_kernel(FieldArgs A)
             float t_frac = 0.0f;
             if constexpr (TEMPORAL) temporal_keyframe(tq[j], k_lo, t_frac);
             float R[8];
+#ifdef CED_FIELD_SKELETON   // diagnostic build: MFMA skeleton only (results are meaningless)
+#pragma unroll
+            for (int i = 0; i < 8; ++i) R[i] = xn[j][i % 3] + (float)i;
+#else
             // slot i of the four lane groups covers levels {i, 2+i, 4+i, 6+i} (i < 2) or {8.., ..}: when they
             // are all dense or all hashed (wave-uniform, decided on the host) only that index form is computed
 #pragma unroll
@@ -436,8 +463,11 @@ __global__ __launch_bounds__(THREADS) void field_kernel(FieldArgs A)
                 else if (mode == 2) hash_level<F16, TEMPORAL, 2>(LC[i], A.table, xn[j], k_lo, t_frac, R[2 * i], R[2 * i + 1]);
                 else hash_level<F16, TEMPORAL, 0>(LC[i], A.table, xn[j], k_lo, t_frac, R[2 * i], R[2 * i + 1]);
             }
+#endif
+#ifndef CED_FIELD_SKELETON
             transpose4(R[0], R[1], R[2], R[3]);
             transpose4(R[4], R[5], R[6], R[7]);
+#endif
 #pragma unroll
             for (int s = 0; s < 8; ++s) B[j][s] = R[s];
             if (TE) {

@@ -142,7 +142,7 @@ struct MarchArgs {
 // contiguous bytes); the workgroup then reserves ONE contiguous output range with a single returning
 // atomic -- a returning atomic on one word sustains only ~88 ops/us on this chip, so one per wave
 // (10^4 per launch) would cost more than the marching itself.
-__global__ void march_alloc_kernel(MarchArgs A)
+__global__ __launch_bounds__(256) void march_alloc_kernel(MarchArgs A)
 {
     extern __shared__ __attribute__((aligned(16))) float2 stage_all[];
     __shared__ int wave_tot[16];
