@@ -39,6 +39,8 @@ def parse():
                     help="per-launch HBM traffic of the field kernel from the rocprofv3 --pmc passes (tools/pmc_summary.py)")
     ap.add_argument("--regime", default="trained")
     ap.add_argument("--max-samples", type=int, default=1024)
+    ap.add_argument("--frames-in-flight", type=int, default=3,
+                    help="independent frames rendered concurrently per GPU (own stream + host thread each)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-stride", type=int, default=1, help="pixel stride of the CPU-baseline ray sample")
     ap.add_argument("--cpu-passes", type=int, default=3, help="how many times the CPU baseline renders its sample")
@@ -113,40 +115,58 @@ def main():
     _lib.lib()
 
     T = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)
-    # one frame per GPU per step: consecutive azimuths of a turntable video
+    # A step renders `lanes` x `world` frames of a turntable video (consecutive azimuths): every lane is
+    # one frame per GPU, its rays dealt tile-cyclically over the ranks; the lanes run concurrently.
+    lanes = max(1, args.frames_in_flight)
     tdt = np.float16 if args.table_dtype == "f16" else np.float32
-    frames = [S.make_scene(args.scene, args.width, args.height, args.regime, azim_deg=30.0 + 12.0 * f, table_dtype=tdt)
-              for f in range(world)]
-    sc = frames[0]
+    n_frames = lanes * world
+    sc = S.make_scene(args.scene, args.width, args.height, args.regime, azim_deg=30.0, table_dtype=tdt)
     cfg = sc["cfg"]
+
+    def frame_rays(f):            # same scene and field, camera azimuth 30 + 12 f degrees
+        if f == 0:
+            return {"origins": sc["origins"], "viewdirs": sc["viewdirs"]}
+        c2w = S.look_at_c2w(cfg["radius"], 30.0, 30.0 + 12.0 * f, cfg["opengl"])
+        o, d = S.make_camera_rays(args.width, args.height, cfg["camera_angle_x"], c2w, cfg["opengl"])
+        return {"origins": o, "viewdirs": d}
+
+    frames = [frame_rays(f) for f in range(n_frames)]
     field = DNGPradianceField.from_params(sc["params"], dev).eval()
+    field._descriptor()
     est = OccGridEstimator(cfg["aabb"], cfg["grid_resolution"], cfg["grid_levels"]).to(dev)
     est.set_binaries(T(sc["binaries"]))
     rk = dict(sc["render"]); rk["render_bkgd"] = T(rk["render_bkgd"])
-    origins = torch.stack([T(f["origins"]) for f in frames])        # [F,H,W,3]
-    viewdirs = torch.stack([T(f["viewdirs"]) for f in frames])
     ts = T(sc["timestamps"])
     from ced_nerf_amd import ops
-    renderer = cdist.ShardedRenderer(field, est, world, rank, dev, max_samples=args.max_samples, render_kwargs=rk)
-    renderer.set_rays(origins, viewdirs)
-    tracer = ops.FrameTracer(capacity=128, with_events=True)     # HIP events around every field launch
-    renderer.tracer = tracer
+    lane_renderers, tracers = [], []
+    for l in range(lanes):
+        fr = frames[l * world:(l + 1) * world]
+        r = cdist.ShardedRenderer(field, est, world, rank, dev, max_samples=args.max_samples, render_kwargs=rk)
+        r.set_rays(torch.stack([T(f["origins"]) for f in fr]), torch.stack([T(f["viewdirs"]) for f in fr]))
+        # HIP events around every field launch; one event set per timed step so nothing is read back
+        # (hipEventElapsedTime) inside the timed region
+        tracers.append([ops.FrameTracer(capacity=96, with_events=True) for _ in range(min(args.steps, 24))])
+        r.tracer = tracers[-1][0]
+        lane_renderers.append(r)
+    renderer = cdist.PipelinedRenderer(lane_renderers)
     field_ms, field_launches, field_samples = [0.0], [0], [0]
+    step_no = [0]
 
     def step():
-        out = renderer.render(ts)
-        # the frame call returns after its last per-iteration sync, so these events have completed
-        ms = tracer.field_ms()
-        field_ms[0] += sum(ms); field_launches[0] += len(ms)
-        field_samples[0] += sum(it["n_new"] for it in tracer.iterations())
-        return out
+        for l, r in enumerate(lane_renderers):
+            r.tracer = tracers[l][step_no[0] % len(tracers[l])]
+        step_no[0] += 1
+        outs = renderer.render(ts)
+        return {"local_samples": sum(o["local_samples"] for o in outs)}
 
     for _ in range(args.warmup):
         step()
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
-    field_ms[0], field_launches[0], field_samples[0] = 0.0, 0, 0
+    step_no[0] = 0
+    ref_event = torch.cuda.Event(enable_timing=True)
+    ref_event.record()
     t0 = time.perf_counter()
     samples_local = 0
     for _ in range(args.steps):
@@ -156,6 +176,25 @@ def main():
     if world > 1:
         dist.barrier()
     dt = time.perf_counter() - t0
+    intervals = []
+    for l in range(lanes):                      # the last min(steps, 24) steps' field launches
+        for tr in tracers[l][:min(args.steps, len(tracers[l]))]:
+            iv = tr.field_intervals(ref_event)
+            intervals += iv
+            field_ms[0] += sum(e - b for b, e in iv); field_launches[0] += len(iv)
+            field_samples[0] += sum(it["n_new"] for it in tr.iterations())
+    # time during which at least one field kernel was executing (frames in flight overlap their launches)
+    intervals.sort()
+    busy_ms, cur_b, cur_e = 0.0, None, None
+    for b, e in intervals:
+        if cur_e is None or b > cur_e:
+            if cur_e is not None:
+                busy_ms += cur_e - cur_b
+            cur_b, cur_e = b, e
+        else:
+            cur_e = max(cur_e, e)
+    if cur_e is not None:
+        busy_ms += cur_e - cur_b
     prof = {"field": {"ms": field_ms[0], "launches": field_launches[0], "units": float(field_samples[0])}}
     tt = torch.tensor([dt, float(samples_local)], device=dev, dtype=torch.float64)
     if world > 1:
@@ -168,7 +207,19 @@ def main():
         if world > 1:
             dist.destroy_process_group()
         return
-    n_rays_step = world * args.width * args.height
+    n_rays_step = n_frames * args.width * args.height
+    # latency of ONE frame rendered alone (no other frame in flight), for reference
+    torch.cuda.synchronize()
+    t1 = time.perf_counter()
+    single_field = {"ms": 0.0, "launches": 0, "units": 0.0}
+    lane_renderers[0].tracer = tracers[0][0]
+    for _ in range(5):
+        lane_renderers[0].render(ts)
+        ms = tracers[0][0].field_ms()
+        single_field["ms"] += sum(ms); single_field["launches"] += len(ms)
+        single_field["units"] += float(sum(it["n_new"] for it in tracers[0][0].iterations()))
+    torch.cuda.synchronize()
+    single_ms = (time.perf_counter() - t1) / 5 * 1e3
     fp16 = sc["params"]["hash"]["table"].dtype == np.float16
     line = {
         "metric": "samples_per_sec (render_image_test, 800x800 D-NeRF lego-shaped synthetic)",
@@ -176,16 +227,23 @@ def main():
         "ms_per_step": 1e3 * dt / args.steps, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
         "dtype": "f32", "data": "synthetic",
         "rays_per_sec": n_rays_step * args.steps / dt,
+        "ms_per_frame": 1e3 * dt / args.steps / lanes, "single_frame_latency_ms": single_ms,
         "samples_per_ray": samples_total / (n_rays_step * args.steps),
         "config": {"workload": f"{args.scene} {args.width}x{args.height} render_image_test max_samples={args.max_samples}, "
                                f"hash L=16 F=2 T=2^21 {'fp16' if fp16 else 'fp32'} table, 64-wide MLPs, "
                                f"{args.regime} params, occupancy 128^3 x{cfg['grid_levels']}",
-                   "frames_per_step": world, "rays_per_step": n_rays_step,
-                   "parallelism": f"rays tile-cyclic over {world} GPU(s) + all-gather of pixels"},
+                   "frames_per_step": n_frames, "frames_in_flight_per_gpu": lanes, "rays_per_step": n_rays_step,
+                   "parallelism": f"{lanes} frame(s) in flight per GPU; each frame's rays tile-cyclic over {world} "
+                                  f"GPU(s) + all-gather of pixels"},
     }
     fk = prof.get("field", None)
     if fk and fk["launches"] > 0:
-        avg_ms = fk["ms"] / fk["launches"]
+        # With several frames in flight their field launches share the chip, so a launch's own
+        # begin->end time includes the others' work.  The effective duration per launch is the time
+        # some field kernel was executing divided by the number of launches; the raw per-launch
+        # average (what rocprofv3 --stats reports per dispatch) is kept beside it.
+        raw_avg_ms = fk["ms"] / fk["launches"]
+        avg_ms = busy_ms / fk["launches"]
         samples_per_launch = fk["units"] / fk["launches"]
         tflops = samples_per_launch * ALG_FLOPS_PER_SAMPLE / (avg_ms * 1e-3) / 1e12
         gbs = samples_per_launch * (ALG_BYTES_PER_SAMPLE_F16 if fp16 else ALG_BYTES_PER_SAMPLE_F32) / (avg_ms * 1e-3) / 1e9
@@ -197,15 +255,26 @@ def main():
                 traffic = k["fetch_bytes_per_launch"] + k["write_bytes_per_launch"]
             except Exception:
                 traffic = None
+        # uncontended figure: the same kernel while only ONE frame is in flight (measured after the timed region)
+        if single_field is not None and single_field["launches"] > 0:
+            s_ms = single_field["ms"] / single_field["launches"]
+            s_tf = single_field["units"] / single_field["launches"] * ALG_FLOPS_PER_SAMPLE / (s_ms * 1e-3) / 1e12
+            line["roofline_single_frame"] = {"bound": "mfma", "achieved": s_tf, "peak": PEAK_F32_MFMA_TFLOPS,
+                                             "unit": "TFLOP/s", "frac": s_tf / PEAK_F32_MFMA_TFLOPS,
+                                             "avg_launch_ms": s_ms, "launches": single_field["launches"]}
         line["roofline"] = {"kernel": "field_kernel (fused DNGPradianceField forward)", "bound": "mfma",
                             "achieved": tflops, "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
                             "frac": tflops / PEAK_F32_MFMA_TFLOPS, "traffic": traffic,
                             "avg_launch_ms": avg_ms, "launches": fk["launches"],
                             "samples_per_launch": samples_per_launch,
-                            "field_share_of_step": fk["ms"] / (1e3 * dt)}
+                            "avg_launch_ms_raw": raw_avg_ms, "field_busy_over_wall": busy_ms / (1e3 * dt * min(args.steps, 24) / args.steps),
+                            "note": "%d frame(s) in flight: avg_launch_ms = (time with a field kernel executing) / "
+                                    "launches; avg_launch_ms_raw = mean begin->end of a launch (overlapping launches "
+                                    "share the chip; this is what rocprofv3 --stats lists); roofline_single_frame = "
+                                    "the kernel with one frame in flight" % lanes}
         line["roofline_hbm"] = {"bound": "hbm", "achieved": gbs, "peak": PEAK_HBM_GBS, "unit": "GB/s",
                                 "frac": gbs / PEAK_HBM_GBS, "traffic": traffic}
-        line["kernel_ms_per_step"] = {k: v["ms"] / args.steps for k, v in prof.items()}
+        line["kernel_ms_per_step"] = {k: v["ms"] / min(args.steps, 24) for k, v in prof.items()}
     if not args.no_cpu_baseline:
         line["cpu_baseline"] = cpu_baseline(sc, args)
         if args.torch_stride > 0:

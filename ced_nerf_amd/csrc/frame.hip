@@ -365,10 +365,22 @@ extern "C" int ced_render_image_test(const ced_field_desc *field, int64_t n_rays
                                      const float *timestamps, int32_t t_per_ray, const float *bkgd, float *rgb,
                                      float *opacity, float *depth, void *workspace, int64_t workspace_bytes,
                                      int64_t *host_stats, int64_t *total_samples_out, ced_frame_trace *trace,
-                                     void *stream_)
+                                     void *field_stream_, void *stream_)
 {
     using namespace ced;
     hipStream_t stream = (hipStream_t)stream_;
+    // Optional separate stream for the field kernel: callers that keep several frames in flight hand
+    // every frame the same field stream, so the MFMA-bound field launches of different frames queue
+    // behind each other (overlapping them buys nothing) while the latency-bound marching / compositing
+    // launches and the host hand-shake of one frame run beside the field kernel of another.
+    hipStream_t fstream = field_stream_ ? (hipStream_t)field_stream_ : stream;
+    const bool split = fstream != stream;
+    static thread_local hipEvent_t ev_to_field = nullptr, ev_from_field = nullptr;
+    if (split && !ev_to_field) {
+        if (hipEventCreateWithFlags(&ev_to_field, hipEventDisableTiming) != hipSuccess ||
+            hipEventCreateWithFlags(&ev_from_field, hipEventDisableTiming) != hipSuccess)
+            return check_launch("render_image_test (event create)");
+    }
     CED_REQUIRE(field != nullptr, "render_image_test: null field descriptor");
     CED_REQUIRE(n_rays >= 0 && n_grids >= 1 && n_grids <= kMaxGrids && res >= 1 && res <= 1024, "render_image_test: bad sizes");
     CED_REQUIRE(n_rays < (1ll << 31) / 4, "render_image_test: too many rays for 32-bit sample indices");
@@ -439,12 +451,20 @@ extern "C" int ced_render_image_test(const ced_field_desc *field, int64_t n_rays
         F.t0 = W.t0; F.t1 = W.t1; F.timestamps = timestamps;
         F.rays_mode = 1; F.t_per_ray = t_per_ray ? 1 : 0; F.want_rgb = 1;
         F.rgb = W.rgbs; F.sigma = W.sigma; F.geo = nullptr;
+        if (split) {
+            (void)hipEventRecord(ev_to_field, stream);
+            (void)hipStreamWaitEvent(fstream, ev_to_field, 0);
+        }
         if (trace && it < trace->capacity && trace->field_begin)
-            (void)hipEventRecord((hipEvent_t)trace->field_begin[it], stream);
-        rc = launch_field(field, F, stream_);
+            (void)hipEventRecord((hipEvent_t)trace->field_begin[it], fstream);
+        rc = launch_field(field, F, (void *)fstream);
         if (rc) return rc;
         if (trace && it < trace->capacity && trace->field_end)
-            (void)hipEventRecord((hipEvent_t)trace->field_end[it], stream);
+            (void)hipEventRecord((hipEvent_t)trace->field_end[it], fstream);
+        if (split) {
+            (void)hipEventRecord(ev_from_field, fstream);
+            (void)hipStreamWaitEvent(stream, ev_from_field, 0);
+        }
 
         hipLaunchKernelGGL(frame_composite_kernel, dim3((unsigned)((n_alive + 255) / 256)), blk, 0, stream, n_alive,
                            cur_list, next_list, next_alive, W.packed, W.t0, W.t1, W.sigma, W.rgbs, rgb, opacity, depth,

@@ -48,12 +48,14 @@ class ShardedRenderer:
         self.render_fn = render_fn or self._hip_render
         self.shape = None
         self.tracer = None             # optional ops.FrameTracer handed to the native frame call
+        self.field_stream = None       # optional stream shared with other in-flight frames (PipelinedRenderer)
         self.force_collective = force_collective   # run the shard/gather/un-permute path even when world == 1
 
     def _hip_render(self, rays_o, rays_d, timestamps):
         from .utils import Rays, render_image_test
         return render_image_test(self.max_samples, self.field, self.estimator, Rays(rays_o, rays_d),
-                                 timestamps=timestamps, tracer=self.tracer, **self.render_kwargs)
+                                 timestamps=timestamps, tracer=self.tracer, field_stream=self.field_stream,
+                                 **self.render_kwargs)
 
     def set_rays(self, origins: torch.Tensor, viewdirs: torch.Tensor) -> None:
         assert origins.ndim == 4 and origins.shape == viewdirs.shape, "rays must be [F,H,W,3]"
@@ -81,10 +83,16 @@ class ShardedRenderer:
         self.gather_index = torch.from_numpy(dest.reshape(-1)).to(o.device)
 
     @torch.no_grad()
-    def render(self, timestamps: torch.Tensor) -> Dict:
-        F, H, W = self.shape
+    def render_local(self, timestamps: torch.Tensor):
+        """Render this rank's shard (no communication)."""
         rgb, op, dp, n_samples = self.render_fn(self.local_o, self.local_d, timestamps)
-        n_samples = int(n_samples)
+        return rgb, op, dp, int(n_samples)
+
+    @torch.no_grad()
+    def gather(self, local) -> Dict:
+        """All-gather the shards' pixels and put them back in raster order (one collective)."""
+        F, H, W = self.shape
+        rgb, op, dp, n_samples = local
         if self.gather_index is None:
             return dict(rgb=rgb.view(F, H, W, 3), opacity=op.view(F, H, W, 1), depth=dp.view(F, H, W, 1),
                         local_samples=n_samples, total_samples=n_samples)
@@ -105,3 +113,55 @@ class ShardedRenderer:
         image = image[:n_rays]
         return dict(rgb=image[:, 0:3].reshape(F, H, W, 3), opacity=image[:, 3:4].reshape(F, H, W, 1),
                     depth=image[:, 4:5].reshape(F, H, W, 1), local_samples=n_samples, total_samples=total)
+
+    @torch.no_grad()
+    def render(self, timestamps: torch.Tensor) -> Dict:
+        return self.gather(self.render_local(timestamps))
+
+
+class PipelinedRenderer:
+    """Several independent ray batches ("lanes", e.g. consecutive frames of a video) in flight at once.
+
+    Each lane is a ShardedRenderer with its own HIP stream and host thread, so the latency-bound
+    marching / compositing launches and the per-iteration host round trip of one frame overlap the
+    MFMA-bound field kernel of another (frames are independent: train_real.py:531-558 renders them
+    one after the other).  Every lane is a complete render_image_test call, so per-frame results
+    are exactly those of rendering the frames one at a time.  Collectives are issued afterwards by
+    the calling thread, lane by lane, i.e. in the same order on every rank."""
+
+    def __init__(self, lanes, share_field_stream: bool = False):
+        from concurrent.futures import ThreadPoolExecutor
+        self.lanes = list(lanes)
+        self.streams = [torch.cuda.Stream(device=l.device) if torch.cuda.is_available() and str(l.device) != "cpu"
+                        else None for l in self.lanes]
+        self.pool = ThreadPoolExecutor(max_workers=len(self.lanes)) if len(self.lanes) > 1 else None
+        if share_field_stream and self.pool is not None and self.streams[0] is not None:
+            # Optional: one stream for every lane's field kernel, so those launches queue instead of
+            # sharing the chip (clean per-launch timings).  Off by default: letting the field kernels of
+            # different frames overlap fills each other's launch tails and is measurably faster.
+            self.field_stream = torch.cuda.Stream(device=self.lanes[0].device)
+            for lane in self.lanes:
+                lane.field_stream = self.field_stream
+
+    def _lane(self, i, timestamps):
+        lane, stream = self.lanes[i], self.streams[i]
+        if stream is None:
+            return lane.render_local(timestamps)
+        with torch.cuda.stream(stream):
+            return lane.render_local(timestamps)
+
+    @torch.no_grad()
+    def render(self, timestamps: torch.Tensor):
+        if self.pool is None:
+            locals_ = [self._lane(0, timestamps)]
+        else:
+            main = torch.cuda.current_stream() if self.streams[0] is not None else None
+            if main is not None:
+                for s in self.streams:
+                    s.wait_stream(main)             # the inputs were produced on the caller's stream
+            futures = [self.pool.submit(self._lane, i, timestamps) for i in range(len(self.lanes))]
+            locals_ = [f.result() for f in futures]
+            if main is not None:
+                for s in self.streams:
+                    main.wait_stream(s)
+        return [lane.gather(loc) for lane, loc in zip(self.lanes, locals_)]

@@ -293,6 +293,11 @@ class FrameTracer:
         return [dict(n_alive=int(self._alive[i]), n_samples=int(self._nsamp[i]), n_new=int(self._samples[i]))
                 for i in range(n)]
 
+    def field_intervals(self, ref: "torch.cuda.Event"):
+        """(begin, end) of every field launch in ms after `ref` (an event recorded earlier on the device)."""
+        n = min(int(self.struct.n_iters), self.capacity)
+        return [(ref.elapsed_time(self.events[i][0]), ref.elapsed_time(self.events[i][1])) for i in range(n)]
+
     def field_ms(self):
         """Per-iteration field-kernel durations (ms); call after the stream has been synchronised."""
         n = min(int(self.struct.n_iters), self.capacity)
@@ -304,8 +309,9 @@ _frame_ws = {}
 
 def render_image_test_native(desc: _lib.FieldDesc, rays_o, rays_d, binaries, aabbs, near_plane, far_plane,
                              render_step_size, cone_angle, early_stop_eps, max_samples, timestamps, t_per_ray, bkgd,
-                             tracer: Optional[FrameTracer] = None):
-    """ced_render_image_test.  Returns (rgb [n,3], opacity [n,1], depth [n,1], total_samples)."""
+                             tracer: Optional[FrameTracer] = None, field_stream: Optional[torch.cuda.Stream] = None):
+    """ced_render_image_test.  Returns (rgb [n,3], opacity [n,1], depth [n,1], total_samples).
+    field_stream: optional stream shared by concurrently rendered frames for their field kernels."""
     _chk(rays_o, torch.float32, "rays_o"); _chk(rays_d, torch.float32, "rays_d")
     _chk(aabbs, torch.float32, "aabbs"); _chk(timestamps, torch.float32, "timestamps")
     _chk(bkgd, torch.float32, "render_bkgd", allow_none=True)
@@ -336,6 +342,7 @@ def render_image_test_native(desc: _lib.FieldDesc, rays_o, rays_d, binaries, aab
                                  float(near_plane), float(far_plane), float(render_step_size), float(cone_angle),
                                  float(early_stop_eps), int(max_samples), _p(timestamps), int(bool(t_per_ray)), _p(bkgd),
                                  _p(rgb), _p(opacity), _p(depth), _p(ws[0]), ws[0].numel(), C.c_void_p(ws[1].data_ptr()),
-                                 C.byref(total), C.byref(tracer.struct) if tracer is not None else None, _stream())
+                                 C.byref(total), C.byref(tracer.struct) if tracer is not None else None,
+                                 C.c_void_p(field_stream.cuda_stream) if field_stream is not None else None, _stream())
     _lib.check(rc, "render_image_test")
     return rgb, opacity, depth, int(total.value)

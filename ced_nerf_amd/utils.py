@@ -139,6 +139,7 @@ def render_image_test(
     early_stop_eps: float = 1e-4,
     timestamps: Optional[torch.Tensor] = None,
     tracer=None,
+    field_stream=None,
 ):
     """Iterative eval renderer with per-iteration early termination (cednerf/utils.py:153-318).
     Returns (rgb, opacity, depth, total_samples).  `alpha_thre` is accepted and unused, as in the
@@ -155,7 +156,7 @@ def render_image_test(
     rgb, opacity, depth, total = ops.render_image_test_native(
         radiance_field._descriptor(), rays_o, rays_d, estimator.binaries, estimator.aabbs.contiguous(), near_plane,
         far_plane, render_step_size, cone_angle, early_stop_eps, max_samples, ts, bool(radiance_field.training), bk,
-        tracer=tracer)
+        tracer=tracer, field_stream=field_stream)
     return (rgb.view((*rays_shape[:-1], -1)), opacity.view((*rays_shape[:-1], -1)),
             depth.view((*rays_shape[:-1], -1)), total)
 

@@ -227,6 +227,9 @@ int64_t ced_render_image_test_workspace_bytes(int64_t n_rays, int32_t n_grids, i
  *   workspace: device scratch of ced_render_image_test_workspace_bytes() bytes;
  *   host_stats: PINNED host memory, >= 32 bytes (per-iteration counters land here);
  *   total_samples_out: host, receives the number of field evaluations (utils.py:307,317).
+ *   field_stream: NULL, or a second stream on which the field kernel is launched (event-ordered with
+ *   `stream`): callers with several frames in flight share one field stream between them so the
+ *   MFMA-bound field launches serialise while everything else of one frame overlaps another's.
  * Unlike the other entry points this one BLOCKS: like the reference loop (utils.py:231) it reads
  * the alive-ray count back once per iteration. */
 int ced_render_image_test(const ced_field_desc *field, int64_t n_rays, const float *rays_o, const float *rays_d,
@@ -236,7 +239,7 @@ int ced_render_image_test(const ced_field_desc *field, int64_t n_rays, const flo
                           const float *timestamps, int32_t t_per_ray, const float *bkgd,
                           float *rgb, float *opacity, float *depth,
                           void *workspace, int64_t workspace_bytes, int64_t *host_stats,
-                          int64_t *total_samples_out, ced_frame_trace *trace, void *stream);
+                          int64_t *total_samples_out, ced_frame_trace *trace, void *field_stream, void *stream);
 
 #ifdef __cplusplus
 }

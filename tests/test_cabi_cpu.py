@@ -47,10 +47,10 @@ def test_argument_errors_are_reported_not_thrown():
     assert L.ced_render_image_test_workspace_bytes(10, 9, 128, 0.0, 16) < 0                                  # too many grids
     tot = C.c_int64(-1)
     assert L.ced_render_image_test(C.byref(d), 0, None, None, None, 1, 128, None, 0.0, 1e10, 5e-3, 0.0, 1e-4, 64, None, 0,
-                                   None, None, None, None, None, 0, None, C.byref(tot), None, None) == 0   # no rays
+                                   None, None, None, None, None, 0, None, C.byref(tot), None, None, None) == 0   # no rays
     assert tot.value == 0
     assert L.ced_render_image_test(C.byref(d), 5, None, None, None, 1, 128, None, 0.0, 1e10, 5e-3, 0.0, 1e-4, 64, None, 0,
-                                   None, None, None, None, None, 0, None, C.byref(tot), None, None) == -1
+                                   None, None, None, None, None, 0, None, C.byref(tot), None, None, None) == -1
 
 
 def test_closed_form_skip_matches_sequential_recurrence(oracle):
