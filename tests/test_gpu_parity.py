@@ -429,3 +429,36 @@ def test_sharded_renderer_collective_path_on_gpu(oracle, full_frame):
     finally:
         if created:
             dist.destroy_process_group()
+
+
+def test_pipelined_frames_equal_sequential_frames(oracle, full_frame):
+    """Three frames in flight (own stream + host thread each) give, frame by frame, the bits of
+    rendering them one after the other: every lane is a complete render_image_test call."""
+    from ced_nerf_amd import synthetic as S
+    from ced_nerf_amd.dist import PipelinedRenderer, ShardedRenderer
+    from ced_nerf_amd.utils import Rays, render_image_test
+    sc, of, oest, f, est, rays, rk = full_frame
+    cfg = sc["cfg"]
+    ts = T(sc["timestamps"])
+    W, H = 320, 240
+    lanes, singles = [], []
+    for k in range(3):
+        c2w = S.look_at_c2w(cfg["radius"], 30.0, 20.0 + 25.0 * k, cfg["opengl"])
+        o, d = S.make_camera_rays(W, H, cfg["camera_angle_x"], c2w, cfg["opengl"])
+        r = ShardedRenderer(f, est, 1, 0, torch.device(DEV), max_samples=1024, render_kwargs=rk)
+        r.set_rays(T(o)[None], T(d)[None])
+        lanes.append(r)
+        singles.append(render_image_test(1024, f, est, Rays(T(o), T(d)), timestamps=ts, **rk))
+    pipe = PipelinedRenderer(lanes)
+    for _ in range(3):                                   # repeat: concurrency bugs are intermittent
+        outs = pipe.render(ts)
+        torch.cuda.synchronize()
+        for out, want in zip(outs, singles):
+            assert out["total_samples"] == want[3] and want[3] > 10000
+            assert torch.equal(out["rgb"][0], want[0]) and torch.equal(out["opacity"][0], want[1])
+            assert torch.equal(out["depth"][0], want[2])
+    shared = PipelinedRenderer(lanes, share_field_stream=True)
+    outs = shared.render(ts)
+    torch.cuda.synchronize()
+    for out, want in zip(outs, singles):
+        assert out["total_samples"] == want[3] and torch.equal(out["rgb"][0], want[0])
