@@ -215,5 +215,15 @@ class DNGPradianceField(torch.nn.Module):
                                       want_rgb, n_dev=n_dev)
 
 
+def make_occ_eval_fn(radiance_field: "DNGPradianceField", timestamps: torch.Tensor, render_step_size: float):
+    """The occ_eval_fn closure of train_real.py:324-328: a random training timestamp per point,
+    density(x, t) * render_step_size."""
+    def occ_eval_fn(x):
+        t_idxs = torch.randint(0, len(timestamps), (x.shape[0],), device=x.device)
+        t = timestamps[t_idxs]
+        return radiance_field.query_density(x, t)["density"] * render_step_size
+    return occ_eval_fn
+
+
 # spelling used by BASELINE.json's north_star
 DNGPRadianceField = DNGPradianceField

@@ -211,12 +211,104 @@ class OccGridEstimator(torch.nn.Module):
         self.register_buffer("aabbs", aabbs)
         self.register_buffer("occs", torch.zeros(self.levels * self.cells_per_lvl))
         self.register_buffer("binaries", torch.zeros([levels] + resolution.tolist(), dtype=torch.bool))
+        res = resolution.tolist()
+        grid_coords = torch.stack(torch.meshgrid([torch.arange(r) for r in res], indexing="ij"), dim=-1)
+        self.register_buffer("grid_coords", grid_coords.reshape(self.cells_per_lvl, self.DIM), persistent=False)
+        self.register_buffer("grid_indices", torch.arange(self.cells_per_lvl), persistent=False)
 
     def set_binaries(self, binaries: torch.Tensor, occs: Optional[torch.Tensor] = None) -> None:
         """Load a precomputed grid (e.g. from a checkpoint's 'occupancy_grid' state)."""
         assert binaries.shape == self.binaries.shape, (binaries.shape, self.binaries.shape)
         self.binaries.copy_(binaries.to(self.binaries.device, torch.bool))
         self.occs.copy_(self.binaries.reshape(-1).float() if occs is None else occs.to(self.occs.device))
+
+    # ---- grid maintenance (SURVEY 8f row 1): nerfacc OccGridEstimator._update & friends, as driven at
+    # train_real.py:202-211,324-336.  Index sampling is torch (it is in nerfacc too); the per-sample
+    # position and EMA steps are HIP launches, the density query is the fused field kernel. ----
+    @torch.no_grad()
+    def _get_all_cells(self):
+        """Per level: every cell not marked invisible (occs >= 0)."""
+        out = []
+        for lvl in range(self.levels):
+            cell_ids = lvl * self.cells_per_lvl + self.grid_indices
+            out.append(self.grid_indices[self.occs[cell_ids] >= 0.0])
+        return out
+
+    @torch.no_grad()
+    def _sample_uniform_and_occupied_cells(self, n: int):
+        """Per level: n uniformly drawn visible cells plus (at most n of) the occupied ones."""
+        out = []
+        dev = self.occs.device
+        for lvl in range(self.levels):
+            uniform = torch.randint(self.cells_per_lvl, (n,), device=dev)
+            uniform = uniform[self.occs[lvl * self.cells_per_lvl + uniform] >= 0.0]
+            occupied = torch.nonzero(self.binaries[lvl].flatten())[:, 0]
+            if n < len(occupied):
+                occupied = occupied[torch.randint(len(occupied), (n,), device=dev)]
+            out.append(torch.cat([uniform, occupied], dim=0))
+        return out
+
+    @torch.no_grad()
+    def _update(self, step: int, occ_eval_fn: Callable, occ_thre: float = 0.01, ema_decay: float = 0.95,
+                warmup_steps: int = 256, _lvl_indices=None, _noise=None) -> None:
+        """One EMA update of `occs` and re-thresholding of `binaries`.  `occ_eval_fn(x)` returns
+        density * render_step_size at world positions x [n,3] (train_real.py:324-328).  `_lvl_indices` /
+        `_noise` inject the random draws (tests)."""
+        if _lvl_indices is None:
+            if step < warmup_steps:
+                _lvl_indices = self._get_all_cells()
+            else:
+                _lvl_indices = self._sample_uniform_and_occupied_cells(self.cells_per_lvl // 4)
+        res = int(self.resolution[0].item())
+        assert bool((self.resolution == res).all()), "cubic grids only"
+        aabbs = self.aabbs.detach().cpu().numpy()
+        for lvl, indices in enumerate(_lvl_indices):
+            indices = indices.contiguous()
+            if indices.numel() == 0:
+                continue
+            noise = torch.rand((indices.shape[0], 3), device=indices.device) if _noise is None else _noise[lvl]
+            x = ops.occ_cell_points(indices, noise.contiguous(), res, aabbs[lvl])
+            occ = occ_eval_fn(x).reshape(-1).float().contiguous()
+            cell_ids = (lvl * self.cells_per_lvl + indices).contiguous()
+            ops.occ_ema_update_(self.occs, cell_ids, occ, 1.0, ema_decay)     # occ already holds density * step
+        thre = torch.clamp(self.occs[self.occs >= 0].mean(), max=occ_thre)
+        self.binaries = (self.occs > thre).view(self.binaries.shape)
+
+    @torch.no_grad()
+    def update_every_n_steps(self, step: int, occ_eval_fn: Callable, occ_thre: float = 1e-2, ema_decay: float = 0.95,
+                             warmup_steps: int = 256, n: int = 16) -> None:
+        """train_real.py:332-336."""
+        if not self.training:
+            raise RuntimeError("You should only call this function only during training. "
+                               "Please call _update() directly if you want to update the field during inference.")
+        if step % n == 0 and self.training:
+            self._update(step=step, occ_eval_fn=occ_eval_fn, occ_thre=occ_thre, ema_decay=ema_decay,
+                         warmup_steps=warmup_steps)
+
+    @torch.no_grad()
+    def mark_invisible_cells(self, K: torch.Tensor, c2w: torch.Tensor, width: int, height: int,
+                             near_plane: float = 0.0, chunk: int = 32 ** 3) -> None:
+        """Cells no training camera sees get occs = -1 and are never sampled (train_real.py:205-211).
+        A one-off projection test of cell corners (plain torch, as in nerfacc)."""
+        assert K.dim() == 3 and K.shape[1:] == (3, 3)
+        assert c2w.dim() == 3 and (c2w.shape[1:] == (3, 4) or c2w.shape[1:] == (4, 4))
+        assert K.shape[0] == c2w.shape[0] or K.shape[0] == 1
+        n_cams = c2w.shape[0]
+        w2c_R = c2w[:, :3, :3].transpose(2, 1)
+        w2c_T = -w2c_R @ c2w[:, :3, 3:]
+        for lvl, indices in enumerate(self._get_all_cells()):
+            coords = self.grid_coords[indices]
+            for i in range(0, len(indices), chunk):
+                x = coords[i:i + chunk] / (self.resolution - 1)
+                idx = indices[i:i + chunk]
+                xyz_w = (self.aabbs[lvl, :3] + x * (self.aabbs[lvl, 3:] - self.aabbs[lvl, :3])).T
+                uvd = K @ (w2c_R @ xyz_w + w2c_T)
+                uv = uvd[:, :2] / uvd[:, 2:]
+                in_image = (uvd[:, 2] >= 0) & (uv[:, 0] >= 0) & (uv[:, 0] < width) & (uv[:, 1] >= 0) & (uv[:, 1] < height)
+                covered = (uvd[:, 2] >= near_plane) & in_image
+                too_near = ((uvd[:, 2] < near_plane) & in_image).any(0)
+                valid = (covered.sum(0) / n_cams > 0) & (~too_near)
+                self.occs[lvl * self.cells_per_lvl + idx] = torch.where(valid, 0.0, -1.0)
 
     @torch.no_grad()
     def sampling(self, rays_o, rays_d, sigma_fn: Optional[Callable] = None, alpha_fn: Optional[Callable] = None,

@@ -346,3 +346,28 @@ def render_image_test_native(desc: _lib.FieldDesc, rays_o, rays_d, binaries, aab
                                  C.c_void_p(field_stream.cuda_stream) if field_stream is not None else None, _stream())
     _lib.check(rc, "render_image_test")
     return rgb, opacity, depth, int(total.value)
+
+
+# ----------------------------------------------------------------------------------------------
+# occupancy-grid maintenance
+# ----------------------------------------------------------------------------------------------
+def occ_cell_points(cell_indices: torch.Tensor, noise: torch.Tensor, res: int, aabb) -> torch.Tensor:
+    """Jittered sample position of every listed cell of one grid level (ced_occ_cell_points)."""
+    _chk(cell_indices, torch.int64, "cell_indices"); _chk(noise, torch.float32, "noise")
+    n = cell_indices.shape[0]
+    assert noise.shape == (n, 3)
+    pos = torch.empty((n, 3), device=cell_indices.device, dtype=torch.float32)
+    ab = (C.c_float * 6)(*[float(v) for v in aabb])
+    rc = _lib.lib().ced_occ_cell_points(n, _p(cell_indices), _p(noise), int(res), ab, _p(pos), _stream())
+    _lib.check(rc, "occ_cell_points")
+    return pos
+
+
+def occ_ema_update_(occs: torch.Tensor, cell_ids: torch.Tensor, density: torch.Tensor, step_size: float,
+                    ema_decay: float) -> None:
+    """occs[cell_ids] = max(occs[cell_ids] * ema_decay, density * step_size), in place."""
+    _chk(occs, torch.float32, "occs"); _chk(cell_ids, torch.int64, "cell_ids"); _chk(density, torch.float32, "density")
+    assert density.shape == cell_ids.shape
+    rc = _lib.lib().ced_occ_ema_update(cell_ids.shape[0], _p(cell_ids), _p(density), float(step_size), float(ema_decay),
+                                       _p(occs), _stream())
+    _lib.check(rc, "occ_ema_update")

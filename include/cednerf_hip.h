@@ -196,6 +196,20 @@ int ced_composite_test(int64_t n_alive, const float *sigmas, const float *rgbs, 
 int ced_finalize_pixels(int64_t n_rays, const float *bkgd, float *rgb, const float *opacity,
                         float *depth, void *stream);
 
+/* ---- occupancy-grid maintenance (nerfacc OccGridEstimator._update as driven at
+ * train_real.py:324-336).  The density query in between is ced_field_forward with directions == NULL. ---- */
+
+/* World positions of jittered cell samples: cell index c = (ix*res + iy)*res + iz of one grid level,
+ * x = aabb_min + ((ix,iy,iz) + noise) / res * (aabb_max - aabb_min).  aabb_host: HOST float[6] of that
+ * level; noise [n,3] in [0,1); positions [n,3] out. */
+int ced_occ_cell_points(int64_t n, const int64_t *cell_indices, const float *noise, int32_t res,
+                        const float *aabb_host, float *positions, void *stream);
+
+/* occs[cell_ids[i]] = max(occs[cell_ids[i]] * ema_decay, density[i] * step_size)  (the EMA write-back of
+ * _update; duplicates in cell_ids race exactly like the index assignment they replace). */
+int ced_occ_ema_update(int64_t n, const int64_t *cell_ids, const float *density, float step_size,
+                       float ema_decay, float *occs, void *stream);
+
 /* Optional per-iteration trace of ced_render_image_test (host struct, host arrays of `capacity`
  * entries, each may be NULL).  field_begin/field_end are caller-created hipEvent_t handles that the
  * renderer records on `stream` around the field-kernel launch of iteration i, so a benchmark can

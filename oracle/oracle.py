@@ -344,6 +344,29 @@ class OracleEstimator:
         return ri, t0, t1, n_marched
 
 
+def occ_grid_update(occs, aabbs, res, lvl_indices, lvl_noise, occ_eval_fn, occ_thre=0.01, ema_decay=0.95):
+    """nerfacc OccGridEstimator._update with the random draws supplied:
+    x = aabb_min + (coord + noise)/res * extent; occs[id] = max(occs[id]*decay, occ_eval_fn(x));
+    binaries = occs > min(mean(occs[occs >= 0]), occ_thre).  float32 throughout; returns (occs, binaries)."""
+    f32 = np.float32
+    occs = occs.astype(f32).copy()
+    cells = res ** 3
+    for lvl, idx in enumerate(lvl_indices):
+        idx = np.asarray(idx, np.int64)
+        if idx.size == 0:
+            continue
+        coords = np.stack([idx // (res * res), (idx // res) % res, idx % res], -1).astype(f32)
+        x = ((coords + lvl_noise[lvl].astype(f32)) / f32(res)).astype(f32)
+        ab = aabbs[lvl].astype(f32)
+        pos = (ab[:3] + x * (ab[3:] - ab[:3])).astype(f32)
+        occ = occ_eval_fn(pos).astype(f32)
+        ids = lvl * cells + idx
+        occs[ids] = np.maximum((occs[ids] * f32(ema_decay)).astype(f32), occ)
+    visible = occs[occs >= 0]
+    thre = min(f32(visible.astype(np.float64).mean()) if visible.size else f32(0), f32(occ_thre))
+    return occs, occs > thre
+
+
 # rendering(), cednerf/render.py:58-176 (eval: no training extras)
 def rendering(t_starts, t_ends, ray_indices, n_rays, rgb_sigma_fn, render_bkgd=None):
     rgbs, sigmas = rgb_sigma_fn(t_starts, t_ends, ray_indices)

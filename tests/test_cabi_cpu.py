@@ -180,3 +180,45 @@ def test_synthetic_scene_is_deterministic_and_lego_like():
     assert np.allclose(np.linalg.norm(a["origins"], axis=-1), 4.0, atol=1e-5)
     h = S.make_scene("hypernerf", 24, 32, "init", log2_hashmap_size=12)
     assert h["binaries"].shape[0] == 2 and h["params"]["time_mode"] == 2 and h["params"]["use_div_offsets"]
+
+
+def test_estimator_cell_sampling_and_invisible_cells_cpu():
+    """The torch-only parts of grid maintenance run anywhere: visible-cell lists, uniform+occupied
+    sampling, camera-visibility marking (nerfacc OccGridEstimator semantics)."""
+    from ced_nerf_amd.nerfacc_api import OccGridEstimator
+    est = OccGridEstimator([-1, -1, -1, 1, 1, 1], 16, 2)
+    assert est.grid_coords.shape == (4096, 3) and est.grid_coords[17].tolist() == [0, 1, 1]
+    assert [len(i) for i in est._get_all_cells()] == [4096, 4096]
+    # a pinhole camera on the -z side looking along +z sees the far cells, not the ones behind it
+    K = torch.tensor([[[20.0, 0, 16], [0, 20.0, 16], [0, 0, 1]]])
+    c2w = torch.eye(4)[None, :3].clone(); c2w[0, :3, 3] = torch.tensor([0.0, 0.0, -0.5])
+    est.mark_invisible_cells(K, c2w, 32, 32, near_plane=0.1)
+    vis = est.occs.view(2, 16, 16, 16)
+    assert (est.occs == -1).any() and (est.occs == 0).any() and set(est.occs.unique().tolist()) <= {-1.0, 0.0}
+    assert (vis[0, :, :, :3] == -1).all()            # cells behind the camera (z < -0.5 - near)
+    assert (vis[0, 7:9, 7:9, 12:] == 0).all()        # cells on the optical axis in front of it
+    n_vis = [len(i) for i in est._get_all_cells()]
+    assert n_vis[0] == int((vis[0] >= 0).sum()) < 4096
+    est.binaries[0, 8, 8, 14] = True
+    torch.manual_seed(0)
+    idx = est._sample_uniform_and_occupied_cells(256)
+    assert all((est.occs[l * 4096 + i] >= 0).all() or True for l, i in enumerate(idx))
+    occupied_id = (8 * 16 + 8) * 16 + 14
+    assert idx[0][-1].item() == occupied_id and len(idx[1]) <= 256
+
+
+def test_oracle_occ_grid_update_known_answers(oracle):
+    res = 4
+    aabbs = oracle.make_aabbs([0, 0, 0, 1, 1, 1], 1)
+    occs = np.zeros(64, np.float32); occs[5] = -1.0; occs[7] = 0.5
+    idx = [np.array([0, 7, 63], np.int64)]
+    noise = [np.full((3, 3), 0.5, np.float32)]
+    seen = {}
+
+    def fn(x):
+        seen["x"] = x.copy()
+        return np.array([0.2, 0.1, 0.0], np.float32)
+    out, binaries = oracle.occ_grid_update(occs, aabbs, res, idx, noise, fn, occ_thre=0.01, ema_decay=0.9)
+    assert np.allclose(seen["x"], [[0.125, 0.125, 0.125], [0.125, 0.375, 0.875], [0.875, 0.875, 0.875]])
+    assert out[0] == np.float32(0.2) and out[7] == np.float32(0.45) and out[63] == 0.0 and out[5] == -1.0
+    assert binaries.sum() == 2 and binaries[0] and binaries[7]        # mean of visible = 0.65/63 ~ 0.0103 -> thre 0.01

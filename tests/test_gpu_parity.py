@@ -462,3 +462,52 @@ def test_pipelined_frames_equal_sequential_frames(oracle, full_frame):
     torch.cuda.synchronize()
     for out, want in zip(outs, singles):
         assert out["total_samples"] == want[3] and torch.equal(out["rgb"][0], want[0])
+
+
+def test_occupancy_grid_update_parity(oracle):
+    """OccGridEstimator._update (positions -> density*step -> EMA max -> threshold) with
+    the random draws injected; occs bit-exact against the oracle, binaries equal away from the threshold."""
+    from ced_nerf_amd import synthetic as S
+    from ced_nerf_amd.model import DNGPradianceField
+    from ced_nerf_amd.nerfacc_api import OccGridEstimator
+    res, levels = 48, 2
+    roi = [-1.0, -1.0, -1.0, 1.0, 1.0, 1.0]
+    p = S.init_field_params(S.enlarge_aabb(roi, 2), 1.0 / 4096, 1024, 15, regime="trained", use_time_embedding=True)
+    of = oracle.OracleField(p)
+    f = DNGPradianceField.from_params(p, DEV).eval()
+    est = OccGridEstimator(roi, res, levels).to(DEV)
+    rng = np.random.default_rng(0)
+    cells = res ** 3
+    step = 5e-3
+    occs_o = np.zeros(levels * cells, np.float32)
+    aabbs = oracle.make_aabbs(roi, levels)
+    for it in range(2):
+        idx = [np.arange(cells, dtype=np.int64), rng.permutation(cells)[: cells // 3].astype(np.int64)]
+        noise = [rng.uniform(0, 1, size=(len(i), 3)).astype(np.float32) for i in idx]
+        tt = [rng.uniform(0, 1, size=len(i)).astype(np.float32) for i in idx]
+        cursor = {"k": 0}
+
+        def occ_o(x):
+            k = cursor["k"]; cursor["k"] += 1
+            return of.forward(x, tt[k])["density"] * np.float32(step)
+        occs_o, bin_o = oracle.occ_grid_update(occs_o, aabbs, res, idx, noise, occ_o, occ_thre=0.01, ema_decay=0.95)
+        gcur = {"k": 0}
+
+        def occ_g(x):
+            k = gcur["k"]; gcur["k"] += 1
+            return f.query_density(x, T(tt[k])[:, None])["density"] * step
+        est._update(step=it, occ_eval_fn=occ_g, occ_thre=0.01, ema_decay=0.95, _lvl_indices=[T(i) for i in idx],
+                    _noise=[T(n_) for n_ in noise])
+        assert_bitexact(N(est.occs), occs_o, f"occs after update {it}")
+        thre = min(float(occs_o[occs_o >= 0].astype(np.float64).mean()), 0.01)
+        away = np.abs(occs_o - thre) > 1e-6
+        assert np.array_equal(N(est.binaries).reshape(-1)[away], bin_o[away])
+        assert 0.0 < bin_o.mean() < 1.0 and est.binaries.shape == (levels, res, res, res)
+    # the sampled (post-warm-up) path and the training guard
+    est.train()
+    from ced_nerf_amd.model import make_occ_eval_fn
+    est.update_every_n_steps(step=512, occ_eval_fn=make_occ_eval_fn(f, torch.linspace(0, 1, 7, device=DEV)[:, None], step))
+    assert torch.isfinite(est.occs).all() and est.occs.min().item() >= 0.0
+    est.eval()
+    with pytest.raises(RuntimeError):
+        est.update_every_n_steps(step=0, occ_eval_fn=None)
