@@ -13,7 +13,7 @@ from typing import List, Optional
 _PKG = os.path.dirname(os.path.abspath(__file__))
 _ROOT = os.path.dirname(_PKG)
 LIB_PATH = os.environ.get("CED_NERF_LIB", os.path.join(_PKG, "libcednerf_hip.so"))
-SOURCES = ["runtime.hip", "march.hip", "composite.hip", "field.hip", "frame.hip", "occgrid.hip"]
+SOURCES = ["runtime.hip", "march.hip", "composite.hip", "field.hip", "frame.hip", "occgrid.hip", "raygen.hip"]
 HIPCC_FLAGS = ["--offload-arch=gfx950", "-O3", "-ffp-contract=off", "-fPIC", "-shared", "-std=c++17"]
 MAX_LEVELS = 16
 
@@ -74,6 +74,9 @@ PROTOTYPES = {
     "ced_finalize_pixels": (C.c_int, [_i64, _vp, _vp, _vp, _vp, _vp]),
     "ced_occ_cell_points": (C.c_int, [_i64, _vp, _vp, _i32, C.POINTER(C.c_float), _vp, _vp]),
     "ced_occ_ema_update": (C.c_int, [_i64, _vp, _vp, _f, _f, _vp, _vp]),
+    "ced_generate_rays_pinhole": (C.c_int, [_i32, _i32, _f, _f, _f, _f, C.POINTER(C.c_float), _i32, _vp, _vp, _vp, _vp]),
+    "ced_generate_rays_hypercam": (C.c_int, [_i32, _i32, C.POINTER(C.c_float), C.POINTER(C.c_float), _f, _f, _f, _f, _f,
+                                             C.POINTER(C.c_float), C.POINTER(C.c_float), _vp, _vp, _vp]),
     "ced_render_image_test_workspace_bytes": (_i64, [_i64, _i32, _i32, _f, _i32]),
     "ced_render_image_test": (C.c_int, [C.POINTER(FieldDesc), _i64, _vp, _vp, _vp, _i32, _i32, _vp, _f, _f, _f, _f, _f,
                                         _i32, _vp, _i32, _vp, _vp, _vp, _vp, _vp, _i64, _vp, C.POINTER(_i64),

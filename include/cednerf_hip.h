@@ -210,6 +210,26 @@ int ced_occ_cell_points(int64_t n, const int64_t *cell_indices, const float *noi
 int ced_occ_ema_update(int64_t n, const int64_t *cell_ids, const float *density, float step_size,
                        float ema_decay, float *occs, void *stream);
 
+/* ---- on-device ray generation: full-frame rays from camera parameters, so no
+ * [H,W,3] x 2 upload per frame.  Outputs [height*width, 3] row-major (pixel x fastest), i.e. Rays of
+ * shape [H,W,3]. ---- */
+
+/* Pinhole camera of datasets/dnerf_synthetic.py:191-221 / gui.py:43-86: pixel (x,y) ->
+ * [(x-cx+.5)/fx, (y-cy+.5)/fy * s, s] (s = -1 OpenGL, +1 OpenCV) rotated by c2w[:3,:3]; origins = c2w[:3,3];
+ * viewdirs = normalised directions.  c2w_host: HOST float[12] ([3][4] row-major); directions may be NULL. */
+int ced_generate_rays_pinhole(int32_t width, int32_t height, float fx, float fy, float cx, float cy,
+                              const float *c2w_host, int32_t opengl, float *origins, float *viewdirs,
+                              float *directions, void *stream);
+
+/* HyperNeRF camera, datasets/hyper_cam.py:210-252 on get_pixel_centers() (:299-303), as used at
+ * datasets/hypernerf.py:172-176: skew / aspect / principal point, radial (k1,k2,k3) + tangential (p1,p2)
+ * undistortion by 10 Newton steps (:22-91), rotation by orientation^T.  orientation_host float[9]
+ * (row-major), position_host float[3], radial3_host / tangential2_host HOST arrays (NULL = none). */
+int ced_generate_rays_hypercam(int32_t width, int32_t height, const float *orientation_host,
+                               const float *position_host, float focal_length, float principal_x, float principal_y,
+                               float skew, float pixel_aspect_ratio, const float *radial3_host,
+                               const float *tangential2_host, float *origins, float *viewdirs, void *stream);
+
 /* Optional per-iteration trace of ced_render_image_test (host struct, host arrays of `capacity`
  * entries, each may be NULL).  field_begin/field_end are caller-created hipEvent_t handles that the
  * renderer records on `stream` around the field-kernel launch of iteration i, so a benchmark can

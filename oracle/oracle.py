@@ -469,3 +469,58 @@ def time_encode(t, move_norm=None, with_exp=False):
     out = np.empty((t.shape[0], 9), np.float32)
     lib().ced_o_time_encode_batch(C.c_int64(t.shape[0]), _p(t), _p(mv), C.c_int(int(with_exp)), _p(out))
     return out
+
+
+# ---------------------------------------------------------------------------------------------
+# ray generation, float32
+# ---------------------------------------------------------------------------------------------
+def pinhole_rays(K, c2w, width, height, opengl=True):
+    """datasets/dnerf_synthetic.py:191-221 / gui.py:43-86.  Returns (origins, viewdirs) [H,W,3]."""
+    f32 = np.float32
+    K = np.asarray(K, f32); c2w = np.asarray(c2w, f32)[:3, :4]
+    x, y = np.meshgrid(np.arange(width, dtype=f32), np.arange(height, dtype=f32), indexing="xy")
+    s = f32(-1.0 if opengl else 1.0)
+    cam = np.stack([(x - K[0, 2] + f32(0.5)) / K[0, 0], (y - K[1, 2] + f32(0.5)) / K[1, 1] * s, np.full_like(x, s)], -1)
+    d = ((cam[..., 0:1] * c2w[:, 0] + cam[..., 1:2] * c2w[:, 1]) + cam[..., 2:3] * c2w[:, 2]).astype(f32)
+    nrm = np.sqrt((d[..., 0] * d[..., 0] + d[..., 1] * d[..., 1]) + d[..., 2] * d[..., 2]).astype(f32)
+    o = np.broadcast_to(c2w[:, 3], d.shape).copy()
+    return o, (d / nrm[..., None]).astype(f32)
+
+
+def hypercam_rays(orientation, position, focal_length, principal_point, image_size, skew=0.0,
+                  pixel_aspect_ratio=1.0, radial_distortion=None, tangential_distortion=None):
+    """datasets/hyper_cam.py:210-252 on the pixel centres (:299-303), Newton undistortion :22-91."""
+    f32 = np.float32
+    R = np.asarray(orientation, f32); pos = np.asarray(position, f32)
+    W, H = int(image_size[0]), int(image_size[1])
+    rad = np.zeros(3, f32) if radial_distortion is None else np.asarray(radial_distortion, f32)
+    tan = np.zeros(2, f32) if tangential_distortion is None else np.asarray(tangential_distortion, f32)
+    f, skew, asp = f32(focal_length), f32(skew), f32(pixel_aspect_ratio)
+    px, py = np.meshgrid(np.arange(W, dtype=f32) + f32(0.5), np.arange(H, dtype=f32) + f32(0.5))
+    y = (py - f32(principal_point[1])) / (f * asp)
+    x = (px - f32(principal_point[0]) - y * skew) / f
+    if rad.any() or tan.any():
+        k1, k2, k3 = rad; p1, p2 = tan
+        xd, yd = x.copy(), y.copy()
+        one, two, three, six = f32(1), f32(2), f32(3), f32(6)
+        for _ in range(10):
+            r = x * x + y * y
+            d = one + r * (k1 + r * (k2 + k3 * r))
+            fx = d * x + two * p1 * x * y + p2 * (r + two * x * x) - xd
+            fy = d * y + two * p2 * x * y + p1 * (r + two * y * y) - yd
+            d_r = k1 + r * (two * k2 + three * k3 * r)
+            d_x = two * x * d_r; d_y = two * y * d_r
+            fx_x = d + d_x * x + two * p1 * y + six * p2 * x
+            fx_y = d_y * x + two * p1 * x + two * p2 * y
+            fy_x = d_x * y + two * p2 * y + two * p1 * x
+            fy_y = d + d_y * y + two * p2 * x + six * p1 * y
+            den = fy_x * fx_y - fx_x * fy_y
+            ok = np.abs(den) > f32(1e-9)
+            safe = np.where(ok, den, one)
+            x = x + np.where(ok, (fx * fy_y - fy * fx_y) / safe, f32(0))
+            y = y + np.where(ok, (fy * fx_x - fx * fy_x) / safe, f32(0))
+    l = np.stack([x, y, np.ones_like(x)], -1)
+    l = l / np.sqrt((l[..., 0] * l[..., 0] + l[..., 1] * l[..., 1]) + l[..., 2] * l[..., 2])[..., None]
+    w = np.stack([(R[0, r] * l[..., 0] + R[1, r] * l[..., 1]) + R[2, r] * l[..., 2] for r in range(3)], -1).astype(f32)
+    w = w / np.sqrt((w[..., 0] * w[..., 0] + w[..., 1] * w[..., 1]) + w[..., 2] * w[..., 2])[..., None]
+    return np.broadcast_to(pos, w.shape).copy(), w.astype(f32)

@@ -44,6 +44,24 @@ def main():
     flat = du.namedtuple_map(lambda r: r.reshape([8] + list(r.shape[2:])), rays)
     np.savez(os.path.join(HERE, "rays_namedtuple.npz"), fields=np.array(du.Rays._fields),
              flat_origins=flat.origins.numpy(), flat_viewdirs=flat.viewdirs.numpy())
+    # HyperNeRF camera rays (datasets/hyper_cam.py): one undistorted and one distorted camera
+    hc = _load("ref_hyper_cam", os.path.join(REF, "datasets", "hyper_cam.py"))
+    rng = np.random.default_rng(0)
+    cams = {}
+    for tag, rad, tan, skew, aspect in (("plain", None, None, 0.0, 1.0),
+                                        ("distorted", [0.05, -0.02, 0.004], [0.0015, -0.002], 0.3, 1.02)):
+        a = rng.normal(size=(3, 3)); q, _ = np.linalg.qr(a)
+        if np.linalg.det(q) < 0:
+            q[:, 0] = -q[:, 0]
+        cam = hc.Camera(orientation=q.astype(np.float32), position=np.array([0.3, -0.2, 1.1], np.float32),
+                        focal_length=55.0, principal_point=np.array([23.5, 17.25], np.float32),
+                        image_size=np.array([48, 36]), skew=skew, pixel_aspect_ratio=aspect,
+                        radial_distortion=rad, tangential_distortion=tan)
+        rays = cam.pixels_to_rays(cam.get_pixel_centers())
+        cams[tag + "_rays"] = rays.astype(np.float32)
+        for k, v in cam.get_parameters().items():
+            cams[tag + "_" + k] = np.asarray(v)
+    np.savez(os.path.join(HERE, "hypercam_rays.npz"), **cams)
     print("wrote", sorted(f for f in os.listdir(HERE) if f.endswith(".npz")))
 
 

@@ -511,3 +511,31 @@ def test_occupancy_grid_update_parity(oracle):
     est.eval()
     with pytest.raises(RuntimeError):
         est.update_every_n_steps(step=0, occ_eval_fn=None)
+
+
+def test_device_ray_generation(oracle):
+    """rays generated on the device from camera parameters -- the HyperNeRF camera
+    against the reference's own outputs (golden), the pinhole camera against the oracle."""
+    import os
+    from ced_nerf_amd import cameras, synthetic as S
+    g = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "hypercam_rays.npz"))
+    for tag in ("plain", "distorted"):
+        kw = dict(orientation=g[tag + "_orientation"], position=g[tag + "_position"],
+                  focal_length=float(g[tag + "_focal_length"]), principal_point=g[tag + "_principal_point"],
+                  image_size=g[tag + "_image_size"], skew=float(g[tag + "_skew"]),
+                  pixel_aspect_ratio=float(g[tag + "_pixel_aspect_ratio"]),
+                  radial_distortion=g[tag + "_radial_distortion"], tangential_distortion=g[tag + "_tangential_distortion"])
+        rays = cameras.hypercam_rays(device=DEV, **kw)
+        assert rays.viewdirs.shape == (36, 48, 3)
+        assert np.abs(N(rays.viewdirs) - g[tag + "_rays"]).max() <= 3e-7            # vs the reference itself
+        wo, wd = oracle.hypercam_rays(**kw)
+        assert np.abs(N(rays.viewdirs) - wd).max() <= 1.2e-7 and np.array_equal(N(rays.origins), wo)
+    for opengl in (True, False):
+        c2w = S.look_at_c2w(4.0, 25.0, 110.0, opengl)
+        W, H = 800, 800
+        focal = 0.5 * W / np.tan(0.5 * 0.6911112070083618)
+        K = np.array([[focal, 0, W / 2.0], [0, focal, H / 2.0], [0, 0, 1]], np.float32)
+        rays = cameras.pinhole_rays(K, c2w, W, H, opengl, device=DEV)
+        wo, wd = oracle.pinhole_rays(K, c2w, W, H, opengl)
+        assert_bitexact(N(rays.origins), wo, "pinhole origins")
+        assert_bitexact(N(rays.viewdirs), wd, "pinhole viewdirs")

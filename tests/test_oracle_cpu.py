@@ -47,6 +47,32 @@ def test_rays_namedtuple_matches_reference_golden():
     assert np.array_equal(flat.origins.numpy(), g["flat_origins"]) and np.array_equal(flat.viewdirs.numpy(), g["flat_viewdirs"])
 
 
+def test_hypercam_rays_match_reference_golden(oracle):
+    """datasets/hyper_cam.py Camera.pixels_to_rays (imported by tests/golden/make_golden.py)."""
+    g = np.load(os.path.join(GOLD, "hypercam_rays.npz"))
+    for tag in ("plain", "distorted"):
+        o, d = oracle.hypercam_rays(g[tag + "_orientation"], g[tag + "_position"], g[tag + "_focal_length"],
+                                    g[tag + "_principal_point"], g[tag + "_image_size"], g[tag + "_skew"],
+                                    g[tag + "_pixel_aspect_ratio"], g[tag + "_radial_distortion"],
+                                    g[tag + "_tangential_distortion"])
+        assert d.shape == g[tag + "_rays"].shape == (36, 48, 3)
+        assert np.abs(d - g[tag + "_rays"]).max() <= 3e-7
+        assert np.allclose(o, g[tag + "_position"])
+    assert np.abs(g["plain_rays"] - g["distorted_rays"]).max() > 1e-3      # the distortion does something
+
+
+def test_pinhole_rays_match_scene_generator(oracle):
+    from ced_nerf_amd import synthetic as S
+    for opengl in (True, False):
+        c2w = S.look_at_c2w(4.0, 30.0, 40.0, opengl)
+        W, H, ang = 50, 30, 0.6911112070083618
+        focal = 0.5 * W / np.tan(0.5 * ang)
+        K = np.array([[focal, 0, W / 2.0], [0, focal, H / 2.0], [0, 0, 1]], np.float32)
+        o, d = oracle.pinhole_rays(K, c2w, W, H, opengl)
+        so, sd = S.make_camera_rays(W, H, ang, c2w, opengl)
+        assert np.abs(o - so).max() == 0 and np.abs(d - sd).max() <= 3e-7
+
+
 # ---- scalar math kernels vs float64 ------------------------------------------------------------
 def test_math_kernels(oracle):
     L = oracle.lib()
