@@ -110,6 +110,7 @@ class DNGPradianceField(torch.nn.Module):
         self._packed: Optional[torch.Tensor] = None
         self._packed_key = None
         self._desc: Optional[_lib.FieldDesc] = None
+        self._desc_lock = __import__("threading").Lock()     # frames in flight share one field
 
     # ---- parameter plumbing -------------------------------------------------------------------
     @classmethod
@@ -137,10 +138,25 @@ class DNGPradianceField(torch.nn.Module):
                     xyz_wrap=[g(p) for p in self.xyz_wrap], mlp_base=[g(p) for p in self.mlp_base],
                     mlp_head=[g(p) for p in self.mlp_head])
 
+    def __getstate__(self):            # copy.deepcopy / pickle: drop the device-side caches and the lock
+        state = self.__dict__.copy()
+        for k in ("_desc_lock", "_desc", "_packed", "_packed_key"):
+            state.pop(k, None)
+        return state
+
+    def __setstate__(self, state):
+        self.__dict__.update(state)
+        self._packed, self._packed_key, self._desc = None, None, None
+        self._desc_lock = __import__("threading").Lock()
+
     def _weights(self):
         return list(self.xyz_wrap) + list(self.mlp_base) + list(self.mlp_head)
 
     def _descriptor(self) -> _lib.FieldDesc:
+        with self._desc_lock:
+            return self._descriptor_locked()
+
+    def _descriptor_locked(self) -> _lib.FieldDesc:
         ws = self._weights()
         key = (tuple((w.data_ptr(), w._version) for w in ws), self.hash_table.data_ptr(), str(self.hash_table.device),
                self.aabb.data_ptr(), self.aabb._version)

@@ -305,6 +305,7 @@ class FrameTracer:
 
 
 _frame_ws = {}
+_frame_ws_lock = __import__("threading").Lock()
 
 
 def render_image_test_native(desc: _lib.FieldDesc, rays_o, rays_d, binaries, aabbs, near_plane, far_plane,
@@ -327,13 +328,15 @@ def render_image_test_native(desc: _lib.FieldDesc, rays_o, rays_d, binaries, aab
     need = int(L.ced_render_image_test_workspace_bytes(n, m, res, float(cone_angle), int(max_samples)))
     if need < 0:
         raise ValueError("render_image_test: unsupported sizes")
+    # one workspace + pinned hand-shake buffer per (device, stream): frames in flight on different
+    # streams (PipelinedRenderer) never share them
     key = (dev.index, torch.cuda.current_stream().cuda_stream)
-    ws = _frame_ws.get(key)
-    n_host = 2 * ((n + 255) // 256) + 2
-    if ws is None or ws[0].numel() < need or ws[1].numel() < n_host:
-        ws = (torch.empty((max(need, 1),), device=dev, dtype=torch.uint8),
-              torch.zeros((n_host,), dtype=torch.int64).pin_memory())
-        _frame_ws[key] = ws
+    with _frame_ws_lock:
+        ws = _frame_ws.get(key)
+        if ws is None or ws[0].numel() < need:
+            ws = (torch.empty((max(need, 1),), device=dev, dtype=torch.uint8),
+                  torch.zeros((8,), dtype=torch.int64).pin_memory())
+            _frame_ws[key] = ws
     rgb = torch.empty((n, 3), device=dev, dtype=torch.float32)
     opacity = torch.empty((n, 1), device=dev, dtype=torch.float32)
     depth = torch.empty((n, 1), device=dev, dtype=torch.float32)
