@@ -539,3 +539,51 @@ def test_device_ray_generation(oracle):
         wo, wd = oracle.pinhole_rays(K, c2w, W, H, opengl)
         assert_bitexact(N(rays.origins), wo, "pinhole origins")
         assert_bitexact(N(rays.viewdirs), wd, "pinhole viewdirs")
+
+
+def test_frame_renderer_edge_cases(oracle):
+    """Empty / ragged / degenerate inputs of render_image_test against the oracle."""
+    from ced_nerf_amd.model import DNGPradianceField
+    from ced_nerf_amd.nerfacc_api import OccGridEstimator
+    from ced_nerf_amd.utils import Rays, render_image_test
+    sc = _scene("dnerf", 37, 23, "trained", log2_hashmap_size=14)          # 851 rays: not a multiple of 64 / 256
+    of, oest, f, est, rays, rk = _setup(oracle, sc)
+    ts = T(sc["timestamps"])
+
+    def both(max_samples, o, d, est_g, est_o, **over):
+        kw = dict(sc["render"]); kw.update(over)
+        kg = dict(rk); kg.update({k: (T(v) if isinstance(v, np.ndarray) else v) for k, v in over.items()})
+        w = oracle.render_image_test(max_samples, of, est_o, o, d, timestamps=sc["timestamps"], **kw)
+        g = render_image_test(max_samples, f, est_g, Rays(T(o), T(d)), timestamps=ts, **kg)
+        assert g[3] == w[3]
+        for i, nm in enumerate(("rgb", "opacity", "depth")):
+            assert g[i].shape == w[i].shape
+            assert_bitexact(N(g[i]), w[i], f"{nm} (max_samples={max_samples})")
+        return w
+    o, d = sc["origins"], sc["viewdirs"]
+    for ms in (1, 2, 7, 64):                    # sample budget binds: rays stop mid-object
+        both(ms, o, d, est, oest)
+    w = both(1024, o.reshape(-1, 3)[:5], d.reshape(-1, 3)[:5], est, oest)       # flat [n,3] rays, n < one wave
+    assert w[0].shape == (5, 3)
+    # empty occupancy grid: nothing to march, pixels = background
+    empty_g = OccGridEstimator(sc["cfg"]["aabb"], 128, 1).to(DEV)
+    empty_o = oracle.OracleEstimator(sc["cfg"]["aabb"], 128, 1, np.zeros_like(sc["binaries"]))
+    w = both(1024, o, d, empty_g, empty_o)
+    assert w[3] == 0 and np.all(w[0] == 1.0)
+    # every ray misses the box; fully occupied grid; black background given as None
+    away = np.tile(np.array([[0.0, 0.0, 1.0]], np.float32), (64, 1))
+    far_o = np.tile(np.array([[5.0, 5.0, 5.0]], np.float32), (64, 1))
+    w = both(1024, far_o, away, est, oest)
+    assert w[3] == 0
+    full_g = OccGridEstimator(sc["cfg"]["aabb"], 128, 1).to(DEV); full_g.set_binaries(torch.ones_like(full_g.binaries))
+    full_o = oracle.OracleEstimator(sc["cfg"]["aabb"], 128, 1, np.ones_like(sc["binaries"]))
+    w = both(96, o[::3, ::3], d[::3, ::3], full_g, full_o)
+    assert w[3] > 1000
+    g = render_image_test(64, f, est, Rays(T(o), T(d)), timestamps=ts, render_step_size=5e-3, render_bkgd=None)
+    wk = dict(sc["render"]); wk["render_bkgd"] = None
+    w = oracle.render_image_test(64, of, oest, o, d, timestamps=sc["timestamps"], **wk)
+    assert_bitexact(N(g[0]), w[0], "rgb without background")
+    with pytest.raises(NotImplementedError):
+        render_image_test(8, f, est, Rays(T(o), T(d)), timestamps=None)
+    with pytest.raises(NotImplementedError, match="cuda"):
+        render_image_test(8, f, est, Rays(torch.from_numpy(o), torch.from_numpy(d)), timestamps=ts)
