@@ -11,11 +11,14 @@
 // ds_read_b128.  The GEMMs run on v_mfma_f32_16x16x4_f32 with D^T = W * X^T (neurons on the
 // accumulator rows, samples on lanes): exact fp32, an ascending-k fused-multiply-add chain,
 // which is what makes sample counts downstream bit-exact against the CPU oracle.  Activations
-// never leave registers: a layer's 16x16 accumulator block becomes the next layer's B operand
-// through a 4x4 lane-group <-> register transpose (2x v_permlane32_swap + 2x v_permlane16_swap).
-// The hash gather is laid out in the same fragment geometry: lane group g owns levels
-// {2g, 2g+1, 8+2g, 9+2g} of its 16 samples, so the gathered features land in B-operand order
-// after two such transposes and the 128 gathers per sample are spread over 4 lanes.
+// never leave registers, and they never move between lanes either: output rows are independent
+// dot products, so the host packs every hidden layer's weight rows such that accumulator row
+// 16nb + 4g + r (lane group g, register r) holds neuron 16nb + 4r + g -- which is exactly the element
+// lane group g must supply as B operand of k-step 4nb + r of the next layer.  A layer's accumulator
+// registers ARE the next layer's B operand (after a one-instruction ReLU), with the ascending-k
+// summation order intact.  The hash gather lives in the same geometry: lane group g owns levels
+// 4i + 2(g&1) + (g>>1), i = 0..3, of its 16 samples (128 gathers per sample spread over 4 lanes) and one
+// v_permlane16_swap per level pair puts the features in operand order.
 #include <cstdlib>
 #include <cstring>
 
@@ -32,6 +35,15 @@ struct LayerShape { int nb; int ks; };
 __host__ __device__ constexpr int ks4_of(int ks) { return (ks + 3) / 4; }
 __host__ __device__ constexpr int layer_floats(int nb, int ks) { return nb * ks4_of(ks) * 256; }
 
+// Output-row placement of mlp_base's last layer: accumulator row p = 4g + r (lane group g, register r)
+// holds output neuron base_out_neuron(p).  Neuron 0 is the raw density, neuron n >= 1 is geometry feature
+// n - 1 = input 3 + n of mlp_head (model.py:455), which must sit where k-step r, lane group g reads it.
+__host__ __device__ constexpr int base_out_neuron(int p)
+{
+    const int g = p >> 2, r = p & 3;
+    return r > 0 ? (4 * r + g - 3) : (g < 3 ? 13 + g : 0);
+}
+
 template <bool TE> struct Blob {
     static constexpr int KS_B0 = TE ? 11 : 8;
     static constexpr int M0 = 0;
@@ -47,20 +59,6 @@ template <bool TE> struct Blob {
 };
 constexpr int kMaxBlobFloats = Blob<true>::TOTAL;
 
-
-// ---- 4x4 transpose between the wave's four 16-lane groups and four registers ------------------
-// out reg s on lane group q  =  in reg q on lane group s
-__device__ __forceinline__ void transpose4(float &r0, float &r1, float &r2, float &r3)
-{
-    auto a = __builtin_amdgcn_permlane32_swap(__float_as_uint(r0), __float_as_uint(r2), false, false);
-    auto b = __builtin_amdgcn_permlane32_swap(__float_as_uint(r1), __float_as_uint(r3), false, false);
-    auto c = __builtin_amdgcn_permlane16_swap(a[0], b[0], false, false);
-    auto d = __builtin_amdgcn_permlane16_swap(a[1], b[1], false, false);
-    r0 = __uint_as_float(c[0]);
-    r1 = __uint_as_float(c[1]);
-    r2 = __uint_as_float(d[0]);
-    r3 = __uint_as_float(d[1]);
-}
 
 // D[j][nb] (16 neurons x 16 samples, neurons 16nb+4g+r on lane group g reg r) =
 //     sum_k W[neuron][k] * B[j][k/4] (k = 4S+g on lane group g), ascending k.
@@ -91,7 +89,7 @@ __device__ __forceinline__ void mlp_layer(const float *__restrict__ wl, int lane
     }
 }
 
-// ReLU (optional) on the accumulator blocks, then transpose them into the next layer's B operand.
+// ReLU (optional) on the accumulator blocks, which then serve as the next layer's B operand.
 template <int NB, bool RELU, int NT>
 __device__ __forceinline__ void to_operand(const f4 (&D)[NT][4], float (&B)[NT][16])
 {
@@ -117,9 +115,8 @@ __device__ __forceinline__ void to_operand(const f4 (&D)[NT][4], float (&B)[NT][
                 }
                 r[q] = v;
             }
-#ifndef CED_FIELD_SKELETON
-            transpose4(r[0], r[1], r[2], r[3]);
-#endif
+            // no lane movement: the host's row placement makes register r of block nb the operand of
+            // k-step 4nb + r (see ced_pack_field_weights)
 #pragma unroll
             for (int s = 0; s < 4; ++s) B[j][4 * nb + s] = r[s];
         }
@@ -312,11 +309,11 @@ __global__ __launch_bounds__(THREADS) void field_kernel(FieldArgs A)
     }
     __syncthreads();
 
-    // the four levels this lane group gathers: {2g, 2g+1, 8+2g, 9+2g}
+    // the four levels this lane group gathers: 4i + 2(g&1) + (g>>1), i = 0..3
     LevelConst LC[4];
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
-        const int lvl = (i < 2) ? (2 * g + i) : (8 + 2 * g + (i - 2));
+        const int lvl = 4 * i + 2 * (g & 1) + (g >> 1);
         const uint32_t *lt = reinterpret_cast<const uint32_t *>(lds + BL::TOTAL) + lvl * 8;
         LC[i].scale = __uint_as_float(lt[0]);
         LC[i].sxb = lt[1];
@@ -454,8 +451,8 @@ __global__ __launch_bounds__(THREADS) void field_kernel(FieldArgs A)
 #pragma unroll
             for (int i = 0; i < 8; ++i) R[i] = xn[j][i % 3] + (float)i;
 #else
-            // slot i of the four lane groups covers levels {i, 2+i, 4+i, 6+i} (i < 2) or {8.., ..}: when they
-            // are all dense or all hashed (wave-uniform, decided on the host) only that index form is computed
+            // slot i of the four lane groups covers levels 4i..4i+3: when they are all dense or all hashed
+            // (wave-uniform, decided on the host) only that index form is computed
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
                 const int mode = (A.level_mode >> (2 * i)) & 3;
@@ -464,19 +461,28 @@ __global__ __launch_bounds__(THREADS) void field_kernel(FieldArgs A)
                 else hash_level<F16, TEMPORAL, 0>(LC[i], A.table, xn[j], k_lo, t_frac, R[2 * i], R[2 * i + 1]);
             }
 #endif
-#ifndef CED_FIELD_SKELETON
-            transpose4(R[0], R[1], R[2], R[3]);
-            transpose4(R[4], R[5], R[6], R[7]);
-#endif
+            // Slot i holds (f0, f1) of level 4i + h on the even lane group 2h (k-step 2i) and of level
+            // 4i + 2 + h on the odd group 2h+1 (k-step 2i+1).  Operand element (k-step S, group g) is
+            // feature g&1 of level 2S + (g>>1): swapping the odd rows of the f0 register with the even rows
+            // of the f1 register leaves k-step 2i in the first and k-step 2i+1 in the second.
 #pragma unroll
-            for (int s = 0; s < 8; ++s) B[j][s] = R[s];
+            for (int i = 0; i < 4; ++i) {
+#ifndef CED_FIELD_SKELETON
+                auto sw = __builtin_amdgcn_permlane16_swap(__float_as_uint(R[2 * i]), __float_as_uint(R[2 * i + 1]), false, false);
+                B[j][2 * i] = __uint_as_float(sw[0]);
+                B[j][2 * i + 1] = __uint_as_float(sw[1]);
+#else
+                B[j][2 * i] = R[2 * i];
+                B[j][2 * i + 1] = R[2 * i + 1];
+#endif
+            }
             if (TE) {
 #pragma unroll
                 for (int S = 8; S < 11; ++S) B[j][S] = time_feature(4 * (S - 8) + g, A.time_mode, tq[j], mnorm[j]);
             }
         }
 
-        // --- mlp_base (32|41)-64-16; accumulator row p holds output neuron (p+13)&15 ---
+        // --- mlp_base (32|41)-64-16; output row placement: see base_out_neuron() ---
         mlp_layer<BL::KS_B0, 4, NT>(lw + BL::B0, lane, B, D);
         to_operand<4, true, NT>(D, B);
         mlp_layer<16, 1, NT>(lw + BL::B1, lane, B, D);
@@ -485,24 +491,25 @@ __global__ __launch_bounds__(THREADS) void field_kernel(FieldArgs A)
 #pragma unroll
         for (int j = 0; j < NT; ++j) {
             const int64_t s = tile * TILE + 16 * j + c;
-            float sg = det_expf(D[j][0][3] - 1.0f);           // density = trunc_exp(raw - 1) * selector
+            float sg = det_expf(D[j][0][0] - 1.0f);           // density = trunc_exp(raw - 1) * selector; raw: group 3, reg 0
             sg = sel[j] ? sg : 0.0f;
-            if (store_lane && s < n_eff) A.sigma[s] = sg;
+            if (g == 3 && s < n_eff) A.sigma[s] = sg;
             if (A.geo && s < n_eff) {
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
-                    const int nidx = (4 * g + r + 13) & 15;
+                    const int nidx = base_out_neuron(4 * g + r);
                     if (nidx >= 1) A.geo[s * 15 + nidx - 1] = D[j][0][r];
                 }
             }
         }
 
         if (A.want_rgb) {
-            // --- head input: [SH(4), geo(15)] (model.py:447-459); k = 4S+g ---
-            to_operand<1, false, NT>(D, B);      // B[j][0..3] = accumulator rows 4s+g
+            // --- head input: [SH(4), geo(15)] (model.py:447-459); k = 4S+g.  The base layer's output rows
+            // were placed so that register r of lane group g is head input 4r + g (r = 1..3) and
+            // 16 + g (r = 0, g < 3); row (g = 3, r = 0) is the raw density, masked out here. ---
 #pragma unroll
             for (int j = 0; j < NT; ++j) {
-                const float geo_tail = (g == 3) ? 0.0f : B[j][0];     // rows 0,1,2 = neurons 13,14,15; row 3 = density
+                const float geo_tail = (g == 3) ? 0.0f : D[j][0][0];
                 float dv[3];
 #pragma unroll
                 for (int a = 0; a < 3; ++a)
@@ -519,6 +526,9 @@ __global__ __launch_bounds__(THREADS) void field_kernel(FieldArgs A)
                 sh = (g == 2) ? (0.48860251190291987f * v[2]) : sh;
                 sh = (g == 3) ? (-0.48860251190291987f * v[0]) : sh;
                 B[j][0] = sh;
+                B[j][1] = D[j][0][1];
+                B[j][2] = D[j][0][2];
+                B[j][3] = D[j][0][3];
                 B[j][4] = geo_tail;
             }
             mlp_layer<5, 4, NT>(lw + BL::H0, lane, B, D);
@@ -632,11 +642,11 @@ int launch_field(const ced_field_desc *d, FieldArgs &A, void *stream)
         A.size[l] = d->hash.size[l];
         A.hashed[l] = d->hash.hashed[l];
     }
-    // per slot i: the levels {2g+i | g} (i < 2) / {8+2g+(i-2) | g}: 1 = all dense, 2 = all hashed, 0 = mixed
+    // per gather slot i: levels 4i..4i+3: 1 = all dense, 2 = all hashed, 0 = mixed
     A.level_mode = 0;
     for (int i = 0; i < 4; ++i) {
         int n_hashed = 0;
-        for (int g = 0; g < 4; ++g) n_hashed += d->hash.hashed[(i < 2) ? (2 * g + i) : (8 + 2 * g + (i - 2))] ? 1 : 0;
+        for (int g = 0; g < 4; ++g) n_hashed += d->hash.hashed[4 * i + g] ? 1 : 0;
         A.level_mode |= (n_hashed == 0 ? 1 : (n_hashed == 4 ? 2 : 0)) << (2 * i);
     }
     // byte offsets are 32-bit
@@ -702,8 +712,9 @@ extern "C" int64_t ced_packed_weight_floats(int use_div_offsets, int time_mode)
     return time_mode ? ced::Blob<true>::TOTAL : ced::Blob<false>::TOTAL;
 }
 
-// Host-side reorder into MFMA A-fragment order: element (row p, input k) of a layer goes to
-// [nb = p/16][q = (k/4)/4][lane = (k%4)*16 + p%16][s = (k/4)%4].
+// Host-side reorder into MFMA A-fragment order: element (accumulator row p, input k) of a layer goes to
+// [nb = p/16][q = (k/4)/4][lane = (k%4)*16 + p%16][s = (k/4)%4]; which neuron row p computes is the
+// layer's placement (natural / hidden / base-out, below).
 extern "C" int ced_pack_field_weights(int use_div_offsets, int time_mode, const float *m_w0, const float *m_w1,
                                       const float *m_w2, const float *m_w3, const float *b_w0, const float *b_w1,
                                       const float *h_w0, const float *h_w1, const float *h_w2, float *out)
@@ -714,7 +725,7 @@ extern "C" int ced_pack_field_weights(int use_div_offsets, int time_mode, const 
     const bool te = time_mode != 0;
     const int64_t total = ced_packed_weight_floats(use_div_offsets, time_mode);
     for (int64_t i = 0; i < total; ++i) out[i] = 0.0f;
-    struct L { const float *w; int n_out, n_in, nb, ks, off; int row_rot; };
+    struct L { const float *w; int n_out, n_in, nb, ks, off; int placement; };   // 0 natural, 1 hidden, 2 base-out
     const int base_in = te ? 41 : 32;
     const int n_mo = use_div_offsets ? 6 : 3;
     const int ksb0 = te ? 11 : 8;
@@ -729,17 +740,20 @@ extern "C" int ced_pack_field_weights(int use_div_offsets, int time_mode, const 
         for (int i = 0; i < 9; ++i) offs[i] = o[i];
     }
     const L layers[9] = {
-        { m_w0, 64, 32, 4, 8, offs[0], 0 },      { m_w1, 64, 64, 4, 16, offs[1], 0 },
-        { m_w2, 64, 64, 4, 16, offs[2], 0 },     { m_w3, n_mo, 64, 1, 16, offs[3], 0 },
-        { b_w0, 64, base_in, 4, ksb0, offs[4], 0 }, { b_w1, 16, 64, 1, 16, offs[5], 13 },
-        { h_w0, 64, 19, 4, 5, offs[6], 0 },      { h_w1, 64, 64, 4, 16, offs[7], 0 },
+        { m_w0, 64, 32, 4, 8, offs[0], 1 },      { m_w1, 64, 64, 4, 16, offs[1], 1 },
+        { m_w2, 64, 64, 4, 16, offs[2], 1 },     { m_w3, n_mo, 64, 1, 16, offs[3], 0 },
+        { b_w0, 64, base_in, 4, ksb0, offs[4], 1 }, { b_w1, 16, 64, 1, 16, offs[5], 2 },
+        { h_w0, 64, 19, 4, 5, offs[6], 1 },      { h_w1, 64, 64, 4, 16, offs[7], 1 },
         { h_w2, 3, 64, 1, 16, offs[8], 0 },
     };
     for (const L &l : layers) {
         const int ks4 = ced::ks4_of(l.ks);
         for (int p = 0; p < l.nb * 16; ++p) {
-            // accumulator row p holds output neuron (p + rot) mod 16 for the rotated layer
-            const int neuron = l.row_rot ? ((p + l.row_rot) & 15) : p;
+            // which output neuron accumulator row p computes.  Hidden layers: row 16nb + 4g + r holds neuron
+            // 16nb + 4r + g, so that the accumulator registers are the next layer's B operand as they are.
+            int neuron = p;
+            if (l.placement == 1) neuron = (p & ~15) | ((p & 3) << 2) | ((p >> 2) & 3);
+            else if (l.placement == 2) neuron = ced::base_out_neuron(p);
             if (neuron >= l.n_out) continue;
             for (int k = 0; k < l.ks * 4; ++k) {
                 if (k >= l.n_in) continue;

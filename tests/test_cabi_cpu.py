@@ -75,14 +75,25 @@ def test_closed_form_skip_matches_sequential_recurrence(oracle):
     assert L.ced_host_skip_march(0.3, 2.5, 0.0, 0.0) == 2.5
 
 
-def _ref_pack(layer_w, n_out_rows, ks, rot=0):
+def _row_neuron(p, placement):
+    """Which output neuron accumulator row p = 16nb + 4g + r computes (the row placement that
+    makes a layer's accumulator registers the next layer's operand without moving data between lanes)."""
+    nb, g, r = p // 16, (p % 16) // 4, p % 4
+    if placement == "hidden":
+        return 16 * nb + 4 * r + g
+    if placement == "base_out":                  # neuron 0 = raw density, n >= 1 = head input 3 + n
+        return 4 * r + g - 3 if r else (13 + g if g < 3 else 0)
+    return p
+
+
+def _ref_pack(layer_w, n_out_rows, ks, placement="natural"):
     """Independent numpy statement of the fragment order: [nb][q][lane][s]."""
     w = np.asarray(layer_w, np.float32)
     nb = (n_out_rows + 15) // 16
     ks4 = (ks + 3) // 4
     out = np.zeros((nb, ks4, 64, 4), np.float32)
     for p in range(nb * 16):
-        neuron = (p + rot) % 16 if rot else p
+        neuron = _row_neuron(p, placement)
         if neuron >= w.shape[0]:
             continue
         for k in range(min(w.shape[1], ks * 4)):
@@ -98,10 +109,13 @@ def test_pack_field_weights_layout(div, tm):
                             use_time_embedding=tm > 0, use_time_attenuation=tm == 2)
     blob = ops.pack_field_weights(bool(div), tm, p["xyz_wrap"], p["mlp_base"], p["mlp_head"])
     ksb0 = 11 if tm else 8
-    parts = [_ref_pack(p["xyz_wrap"][0], 64, 8), _ref_pack(p["xyz_wrap"][1], 64, 16), _ref_pack(p["xyz_wrap"][2], 64, 16),
-             _ref_pack(p["xyz_wrap"][3], 16, 16), _ref_pack(p["mlp_base"][0], 64, ksb0),
-             _ref_pack(p["mlp_base"][1], 16, 16, rot=13), _ref_pack(p["mlp_head"][0], 64, 5),
-             _ref_pack(p["mlp_head"][1], 64, 16), _ref_pack(p["mlp_head"][2], 16, 16)]
+    H = "hidden"
+    parts = [_ref_pack(p["xyz_wrap"][0], 64, 8, H), _ref_pack(p["xyz_wrap"][1], 64, 16, H), _ref_pack(p["xyz_wrap"][2], 64, 16, H),
+             _ref_pack(p["xyz_wrap"][3], 16, 16), _ref_pack(p["mlp_base"][0], 64, ksb0, H),
+             _ref_pack(p["mlp_base"][1], 16, 16, "base_out"), _ref_pack(p["mlp_head"][0], 64, 5, H),
+             _ref_pack(p["mlp_head"][1], 64, 16, H), _ref_pack(p["mlp_head"][2], 16, 16)]
+    assert sorted(_row_neuron(q, "base_out") for q in range(16)) == list(range(16))
+    assert sorted(_row_neuron(q, H) for q in range(64)) == list(range(64))
     want = np.concatenate(parts)
     assert blob.shape == want.shape == ((22528 if tm else 21504),)
     assert np.array_equal(blob, want)
