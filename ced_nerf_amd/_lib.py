@@ -13,7 +13,10 @@ from typing import List, Optional
 _PKG = os.path.dirname(os.path.abspath(__file__))
 _ROOT = os.path.dirname(_PKG)
 LIB_PATH = os.environ.get("CED_NERF_LIB", os.path.join(_PKG, "libcednerf_hip.so"))
-SOURCES = ["runtime.hip", "march.hip", "composite.hip", "field.hip", "frame.hip", "occgrid.hip", "raygen.hip"]
+SOURCES = ["runtime.hip", "march.hip", "composite.hip", "field.hip", "field_half.hip", "frame.hip", "occgrid.hip",
+           "raygen.hip"]
+MLP_F32, MLP_F16X2, MLP_F16 = 0, 1, 2          # ced_field_desc.mlp_precision
+MLP_PRECISIONS = {"f32": MLP_F32, "f16x2": MLP_F16X2, "f16": MLP_F16}
 HIPCC_FLAGS = ["--offload-arch=gfx950", "-O3", "-ffp-contract=off", "-fPIC", "-shared", "-std=c++17"]
 MAX_LEVELS = 16
 
@@ -32,7 +35,7 @@ class FieldDesc(C.Structure):
     """ced_field_desc"""
     _fields_ = [
         ("aabb", C.c_float * 6), ("moving_step", C.c_float), ("use_div_offsets", C.c_int32),
-        ("time_mode", C.c_int32), ("reserved", C.c_int32),
+        ("time_mode", C.c_int32), ("mlp_precision", C.c_int32),
         ("packed_weights", C.c_void_p), ("packed_floats", C.c_uint64),
         ("hash", HashDesc),
     ]
@@ -57,6 +60,8 @@ PROTOTYPES = {
     "ced_set_option": (C.c_int, [C.c_char_p, C.c_int]),
     "ced_packed_weight_floats": (_i64, [C.c_int, C.c_int]),
     "ced_pack_field_weights": (C.c_int, [C.c_int, C.c_int] + [_vp] * 10),
+    "ced_packed_weight_words": (_i64, [C.c_int, C.c_int, C.c_int]),
+    "ced_pack_field_weights_half": (C.c_int, [C.c_int, C.c_int, C.c_int] + [_vp] * 10),
     "ced_ray_aabb_intersect": (C.c_int, [_i64, _vp, _vp, _i32, _vp, _f, _f, _f, _vp, _vp, _vp, _vp]),
     "ced_traverse_grids": (C.c_int, [_i64, _vp, _vp, _vp, _i32, _i32, _vp, _vp, _vp, _f, _f, _i32, _vp, _vp, _vp, _vp,
                                      _i32, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
@@ -88,7 +93,7 @@ def build(force: bool = False, verbose: bool = False) -> str:
     """Compile every HIP source for gfx950 into the in-tree shared library (hipcc cross-compiles
     without a GPU)."""
     srcs = [os.path.join(_PKG, "csrc", s) for s in SOURCES]
-    deps = srcs + [os.path.join(_PKG, "csrc", h) for h in ("ced_common.hpp", "march_core.hpp", "field_args.hpp")] + [ os.path.join(_ROOT, "include", "cednerf_hip.h")]
+    deps = srcs + [os.path.join(_PKG, "csrc", h) for h in ("ced_common.hpp", "march_core.hpp", "field_args.hpp", "field_device.hpp")] + [ os.path.join(_ROOT, "include", "cednerf_hip.h")]
     if not force and os.path.exists(LIB_PATH) and all(os.path.getmtime(LIB_PATH) >= os.path.getmtime(d) for d in deps):
         return LIB_PATH
     hipcc = os.environ.get("HIPCC", "hipcc")

@@ -24,10 +24,9 @@
 
 #include "ced_common.hpp"
 #include "field_args.hpp"
+#include "field_device.hpp"
 
 namespace ced {
-
-typedef float f4 __attribute__((ext_vector_type(4)));
 
 
 // ---- packed weight blob: layer l stored as [nb][ks4][lane 64][4] floats ----------------------
@@ -123,157 +122,6 @@ __device__ __forceinline__ void to_operand(const f4 (&D)[NT][4], float (&B)[NT][
     }
 }
 
-// Per-level constants, pre-multiplied by the table's bytes per entry (a power of two), so the
-// corner arithmetic below produces byte offsets directly: the xor-hash commutes with the shift
-// ((a^b) << s == (a<<s) ^ (b<<s)) and the dense index is linear.
-struct LevelConst {
-    float scale;
-    uint32_t sxb, syb, szb;   // per-axis multipliers in bytes: (1, p1, p2) * EB when hashed, (1, res, res^2) * EB when dense
-    uint32_t offb;            // first byte of the level
-    uint32_t sizeb;           // level size in bytes (dense wrap-around)
-    uint32_t maskb;           // (size - 1) * EB (hashed levels: size is a power of two)
-    uint32_t hashed;
-};
-
-template <bool F16, bool TEMPORAL> struct EntryBytes { static constexpr uint32_t value = (F16 ? 4u : 8u) * (TEMPORAL ? 4u : 1u); };
-
-__device__ __forceinline__ LevelConst make_level(float scale, uint32_t res, uint32_t offset, uint32_t size, uint32_t hashed,
-                                                 uint32_t eb)
-{
-    LevelConst L;
-    L.scale = scale;
-    L.sxb = eb;
-    L.syb = (hashed ? 2654435761u : res) * eb;
-    L.szb = (hashed ? 805459861u : res * res) * eb;
-    L.offb = offset * eb;
-    L.sizeb = size * eb;
-    L.maskb = (size - 1u) * eb;
-    L.hashed = hashed;
-    return L;
-}
-
-// Trilinear gather of one level for one point (hash_encoder_half.py:112-161; temporal variant
-// hash_encoder_inter.py:148-197).  x already clamped to [0,1].  MODE: 0 = this lane's level may be
-// dense or hashed (both index forms computed, selected per lane), 1 = dense, 2 = hashed.
-template <bool F16, bool TEMPORAL, int MODE>
-__device__ __forceinline__ void hash_level(const LevelConst &L, const void *__restrict__ table, const float (&x)[3],
-                                           int k_lo, float t_frac, float &f0, float &f1)
-{
-    uint32_t g[3];
-    float fr[3], om[3];
-#pragma unroll
-    for (int a = 0; a < 3; ++a) {
-        float p = x[a] * L.scale + 0.5f;
-        float fl = __builtin_floorf(p);
-        g[a] = (uint32_t)fl;
-        fr[a] = p - fl;
-        om[a] = 1.0f - fr[a];
-    }
-    const uint32_t xs[2] = { g[0] * L.sxb, g[0] * L.sxb + L.sxb };
-    const uint32_t ys[2] = { g[1] * L.syb, g[1] * L.syb + L.syb };
-    const uint32_t zs[2] = { g[2] * L.szb, g[2] * L.szb + L.szb };
-    const bool hashed = L.hashed != 0;
-    // y/z combinations are shared by the two x corners
-    uint32_t yz_x[4], yz_a[4];
-#pragma unroll
-    for (int q = 0; q < 4; ++q) {
-        if constexpr (MODE != 1) yz_x[q] = ys[q & 1] ^ zs[q >> 1];
-        if constexpr (MODE != 2) yz_a[q] = ys[q & 1] + zs[q >> 1];
-    }
-    const float wxy[4] = { om[0] * om[1], fr[0] * om[1], om[0] * fr[1], fr[0] * fr[1] };   // index cx + 2*cy
-    uint32_t off[8];
-    float w[8];
-#pragma unroll
-    for (int c = 0; c < 8; ++c) {
-        const int cx = c & 1, cy = (c >> 1) & 1, cz = (c >> 2) & 1;
-        uint32_t hb = 0, db = 0;
-        if constexpr (MODE != 1) hb = (xs[cx] ^ yz_x[cy + 2 * cz]) & L.maskb;
-        if constexpr (MODE != 2) {
-            const uint32_t dx = xs[cx] + yz_a[cy + 2 * cz];
-            db = (dx >= L.sizeb) ? dx - L.sizeb : dx;
-        }
-        const uint32_t idxb = (MODE == 1) ? db : (MODE == 2) ? hb : (hashed ? hb : db);
-        off[c] = L.offb + idxb;
-        w[c] = wxy[cx + 2 * cy] * (cz ? fr[2] : om[2]);
-    }
-    const char *tb = reinterpret_cast<const char *>(table);
-    float v0[8], v1[8];
-    if constexpr (!TEMPORAL) {
-        if constexpr (!F16) {
-#pragma unroll
-            for (int c = 0; c < 8; ++c) {
-                const float2 v = *reinterpret_cast<const float2 *>(tb + off[c]);
-                v0[c] = v.x; v1[c] = v.y;
-            }
-        } else {
-#pragma unroll
-            for (int c = 0; c < 8; ++c) {
-                const uint32_t v = *reinterpret_cast<const uint32_t *>(tb + off[c]);
-                v0[c] = half_bits_to_float((uint16_t)(v & 0xffffu));
-                v1[c] = half_bits_to_float((uint16_t)(v >> 16));
-            }
-        }
-    } else {
-        const float omt = 1.0f - t_frac;
-        const uint32_t kb = (uint32_t)k_lo * (F16 ? 4u : 8u);      // byte offset of key-frame k_lo inside the entry
-        if constexpr (!F16) {
-#pragma unroll
-            for (int c = 0; c < 8; ++c) {
-                const float2 lo = *reinterpret_cast<const float2 *>(tb + off[c] + kb);
-                const float2 hi = *reinterpret_cast<const float2 *>(tb + off[c] + kb + 8u);
-                v0[c] = lo.x * omt + hi.x * t_frac;
-                v1[c] = lo.y * omt + hi.y * t_frac;
-            }
-        } else {
-#pragma unroll
-            for (int c = 0; c < 8; ++c) {
-                const uint32_t lo = *reinterpret_cast<const uint32_t *>(tb + off[c] + kb);
-                const uint32_t hi = *reinterpret_cast<const uint32_t *>(tb + off[c] + kb + 4u);
-                float a0 = half_bits_to_float((uint16_t)(lo & 0xffffu)), a1 = half_bits_to_float((uint16_t)(lo >> 16));
-                float b0 = half_bits_to_float((uint16_t)(hi & 0xffffu)), b1 = half_bits_to_float((uint16_t)(hi >> 16));
-                v0[c] = a0 * omt + b0 * t_frac;
-                v1[c] = a1 * omt + b1 * t_frac;
-            }
-        }
-    }
-    float acc0 = 0.0f, acc1 = 0.0f;
-#pragma unroll
-    for (int c = 0; c < 8; ++c) {
-        acc0 = __builtin_fmaf(w[c], v0[c], acc0);
-        acc1 = __builtin_fmaf(w[c], v1[c], acc1);
-    }
-    f0 = acc0;
-    f1 = acc1;
-}
-
-__device__ __forceinline__ void temporal_keyframe(float tq, int &k_lo, float &t_frac)
-{
-    float ts = tq * 3.0f;
-    float fl = __builtin_floorf(ts);
-    t_frac = ts - fl;
-    fl = __builtin_fminf(fl, 2.0f);
-    k_lo = (int)fl;
-}
-
-// feature idx (0..8, >8 -> 0) of the 9-wide time encoding (cednerf/encoder.py:6-44 / :46-90)
-__device__ __forceinline__ float time_feature(int idx, int time_mode, float t, float mn)
-{
-    const float HALF_PI = 1.57079637050628662f;
-    if (idx == 0) return t;
-    if (idx > 8) return 0.0f;
-    int k, ph;
-    if (time_mode == 1) { k = (idx - 1) & 3; ph = (idx - 1) >> 2; }
-    else { k = (idx - 1) >> 1; ph = (idx - 1) & 1; }
-    float xb = t * (float)(1 << k);
-    float arg = ph ? (xb + HALF_PI) : xb;
-    float s = det_sinf(arg);
-    if (time_mode == 2) {
-        float att = det_expf(-1.0f * (mn * (float)(k * (1 << k))));
-        s = s * att;
-    }
-    return s;
-}
-
 // NT: 16-sample MFMA column tiles per wave iteration; THREADS: workgroup size (one workgroup per CU)
 template <bool TE, bool F16, bool TEMPORAL, int NT, int THREADS>
 __global__ __launch_bounds__(THREADS) void field_kernel(FieldArgs A)
@@ -297,33 +145,11 @@ __global__ __launch_bounds__(THREADS) void field_kernel(FieldArgs A)
             uint32_t *lt = reinterpret_cast<uint32_t *>(lds + BL::TOTAL);
             const LevelConst L = make_level(A.scale[tid], A.res[tid], A.offset[tid], A.size[tid], A.hashed[tid],
                                             EntryBytes<F16, TEMPORAL>::value);
-            lt[tid * 8 + 0] = __float_as_uint(L.scale);
-            lt[tid * 8 + 1] = L.sxb;
-            lt[tid * 8 + 2] = L.syb;
-            lt[tid * 8 + 3] = L.szb;
-            lt[tid * 8 + 4] = L.offb;
-            lt[tid * 8 + 5] = L.sizeb;
-            lt[tid * 8 + 6] = L.maskb;
-            lt[tid * 8 + 7] = L.hashed;
+            store_level(lt + tid * 8, L);
         }
     }
     __syncthreads();
 
-    // the four levels this lane group gathers: 4i + 2(g&1) + (g>>1), i = 0..3
-    LevelConst LC[4];
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        const int lvl = 4 * i + 2 * (g & 1) + (g >> 1);
-        const uint32_t *lt = reinterpret_cast<const uint32_t *>(lds + BL::TOTAL) + lvl * 8;
-        LC[i].scale = __uint_as_float(lt[0]);
-        LC[i].sxb = lt[1];
-        LC[i].syb = lt[2];
-        LC[i].szb = lt[3];
-        LC[i].offb = lt[4];
-        LC[i].sizeb = lt[5];
-        LC[i].maskb = lt[6];
-        LC[i].hashed = lt[7];
-    }
 
     int64_t n_eff = A.n;
     if (A.n_dev) {
@@ -440,27 +266,47 @@ __global__ __launch_bounds__(THREADS) void field_kernel(FieldArgs A)
             mnorm[j] = TE ? __builtin_sqrtf((mv[0] * mv[0] + mv[1] * mv[1]) + mv[2] * mv[2]) : 0.0f;
         }
 
-        // --- hash gather: this lane's 4 levels for each of its 4 samples, then into operand order ---
+        // --- hash gather: this lane's 4 levels for each of its samples, then into operand order ---
+        float R[NT][8];
+        int k_lo[NT];
+        float t_frac[NT];
 #pragma unroll
         for (int j = 0; j < NT; ++j) {
-            int k_lo = 0;
-            float t_frac = 0.0f;
-            if constexpr (TEMPORAL) temporal_keyframe(tq[j], k_lo, t_frac);
-            float R[8];
+            k_lo[j] = 0;
+            t_frac[j] = 0.0f;
+            if constexpr (TEMPORAL) temporal_keyframe(tq[j], k_lo[j], t_frac[j]);
+        }
+        const uint32_t *const ltab = reinterpret_cast<const uint32_t *>(lw + BL::TOTAL);
 #ifdef CED_FIELD_SKELETON   // diagnostic build: MFMA skeleton only (results are meaningless)
 #pragma unroll
-            for (int i = 0; i < 8; ++i) R[i] = xn[j][i % 3] + (float)i;
-#else
-            // slot i of the four lane groups covers levels 4i..4i+3: when they are all dense or all hashed
-            // (wave-uniform, decided on the host) only that index form is computed
+        for (int j = 0; j < NT; ++j)
 #pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                const int mode = (A.level_mode >> (2 * i)) & 3;
-                if (mode == 1) hash_level<F16, TEMPORAL, 1>(LC[i], A.table, xn[j], k_lo, t_frac, R[2 * i], R[2 * i + 1]);
-                else if (mode == 2) hash_level<F16, TEMPORAL, 2>(LC[i], A.table, xn[j], k_lo, t_frac, R[2 * i], R[2 * i + 1]);
-                else hash_level<F16, TEMPORAL, 0>(LC[i], A.table, xn[j], k_lo, t_frac, R[2 * i], R[2 * i + 1]);
+            for (int i = 0; i < 8; ++i) R[j][i] = xn[j][i % 3] + (float)i;
+#else
+        // gather slot i of lane group g is level 4i + 2(g&1) + (g>>1): slot i spans levels 4i..4i+3 across the
+        // wave, and when those are all dense or all hashed (wave-uniform, decided on the host) only that index
+        // form is computed.  The level's constants come from LDS here rather than living in registers.
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const LevelConst L = load_level(ltab + (4 * i + 2 * (g & 1) + (g >> 1)) * 8);
+            const int mode = (A.level_mode >> (2 * i)) & 3;
+            if (mode == 1) {
+#pragma unroll
+                for (int j = 0; j < NT; ++j)
+                    hash_level<F16, TEMPORAL, 1>(L, A.table, xn[j], k_lo[j], t_frac[j], R[j][2 * i], R[j][2 * i + 1]);
+            } else if (mode == 2) {
+#pragma unroll
+                for (int j = 0; j < NT; ++j)
+                    hash_level<F16, TEMPORAL, 2>(L, A.table, xn[j], k_lo[j], t_frac[j], R[j][2 * i], R[j][2 * i + 1]);
+            } else {
+#pragma unroll
+                for (int j = 0; j < NT; ++j)
+                    hash_level<F16, TEMPORAL, 0>(L, A.table, xn[j], k_lo[j], t_frac[j], R[j][2 * i], R[j][2 * i + 1]);
             }
+        }
 #endif
+#pragma unroll
+        for (int j = 0; j < NT; ++j) {
             // Slot i holds (f0, f1) of level 4i + h on the even lane group 2h (k-step 2i) and of level
             // 4i + 2 + h on the odd group 2h+1 (k-step 2i+1).  Operand element (k-step S, group g) is
             // feature g&1 of level 2S + (g>>1): swapping the odd rows of the f0 register with the even rows
@@ -468,12 +314,12 @@ __global__ __launch_bounds__(THREADS) void field_kernel(FieldArgs A)
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
 #ifndef CED_FIELD_SKELETON
-                auto sw = __builtin_amdgcn_permlane16_swap(__float_as_uint(R[2 * i]), __float_as_uint(R[2 * i + 1]), false, false);
+                auto sw = __builtin_amdgcn_permlane16_swap(__float_as_uint(R[j][2 * i]), __float_as_uint(R[j][2 * i + 1]), false, false);
                 B[j][2 * i] = __uint_as_float(sw[0]);
                 B[j][2 * i + 1] = __uint_as_float(sw[1]);
 #else
-                B[j][2 * i] = R[2 * i];
-                B[j][2 * i + 1] = R[2 * i + 1];
+                B[j][2 * i] = R[j][2 * i];
+                B[j][2 * i + 1] = R[j][2 * i + 1];
 #endif
             }
             if (TE) {
@@ -624,9 +470,11 @@ int launch_field(const ced_field_desc *d, FieldArgs &A, void *stream)
     }
     CED_REQUIRE(d->time_mode >= 0 && d->time_mode <= 2, "field_forward: time_mode=%d", d->time_mode);
     CED_REQUIRE(d->packed_weights != nullptr, "field_forward: null packed_weights");
-    CED_REQUIRE((int64_t)d->packed_floats == ced_packed_weight_floats(d->use_div_offsets, d->time_mode),
-                "field_forward: packed_floats=%llu does not match this configuration",
-                (unsigned long long)d->packed_floats);
+    CED_REQUIRE(d->mlp_precision >= CED_MLP_F32 && d->mlp_precision <= CED_MLP_F16, "field_forward: mlp_precision=%d",
+                d->mlp_precision);
+    CED_REQUIRE((int64_t)d->packed_floats == ced_packed_weight_words(d->use_div_offsets, d->time_mode, d->mlp_precision),
+                "field_forward: packed_floats=%llu does not match this configuration (mlp_precision %d)",
+                (unsigned long long)d->packed_floats, d->mlp_precision);
     for (int i = 0; i < 6; ++i) A.aabb[i] = d->aabb[i];
     A.moving_step = d->moving_step;
     A.use_div = d->use_div_offsets ? 1 : 0;
@@ -653,6 +501,10 @@ int launch_field(const ced_field_desc *d, FieldArgs &A, void *stream)
     CED_REQUIRE(d->hash.total_entries * (uint64_t)((A.table_dtype ? 4 : 8) * (A.temporal ? 4 : 1)) < (1ull << 32),
                 "field_forward: hash table larger than 4 GiB");
     A.stagger = g_field_stagger;
+    if (d->mlp_precision != CED_MLP_F32) {
+        // the half kernels gather level 4i + g in slot i: the same slot -> level-range mapping as above
+        return launch_field_half(A, d->time_mode, d->mlp_precision, stream);
+    }
     const int variant = g_field_variant;
     auto launch = [&](auto kernel, int nt, int threads) {
         const int64_t n_tiles = (A.n + 16 * nt - 1) / (16 * nt);
@@ -695,6 +547,11 @@ extern "C" int ced_set_option(const char *key, int value)
     }
     if (strcmp(key, "march_early_out") == 0) {
         ced::g_march_early_out = value != 0;
+        return CED_OK;
+    }
+    if (strcmp(key, "half_variant") == 0) {
+        CED_REQUIRE(value >= 0 && value <= 2, "set_option: half_variant must be 0..2");
+        ced::set_half_variant(value);
         return CED_OK;
     }
     if (strcmp(key, "field_variant") == 0) {

@@ -19,7 +19,7 @@ struct FieldArgs {
     float aabb[6];
     float moving_step;
     int use_div, time_mode;
-    const float *weights;
+    const void *weights;                              // packed blob of the descriptor's mlp_precision
     int table_dtype, temporal;
     int stagger;                                      // start-up phase offset between SIMD-mates (s_sleep(127) units)
     int level_mode;                                   // 2 bits per gather slot: 0 mixed, 1 all dense, 2 all hashed
@@ -32,5 +32,8 @@ extern bool g_march_early_out;
 
 // Fills the field/hash parts of A from the descriptor, validates, and launches on `stream`.
 int launch_field(const ced_field_desc *d, FieldArgs &A, void *stream);
+// field_half.hip: the f16x2 / f16 MLP variants (A already filled by launch_field)
+int launch_field_half(FieldArgs &A, int time_mode, int precision, void *stream);
+void set_half_variant(int v);
 
 }  // namespace ced

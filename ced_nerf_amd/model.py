@@ -55,6 +55,7 @@ class DNGPradianceField(torch.nn.Module):
         hash_dtype: torch.dtype = torch.float32,
         temporal_hash: bool = False,
         seed: Optional[int] = None,
+        mlp_precision: str = "f32",
     ) -> None:
         super().__init__()
         if not isinstance(aabb, torch.Tensor):
@@ -91,6 +92,7 @@ class DNGPradianceField(torch.nn.Module):
         self.hash_cfg = dict(base_res=base_resolution, max_res=dst_resolution, n_levels=n_levels,
                              log2_hashmap_size=log2_hashmap_size, temporal=bool(temporal_hash))
         self.time_mode = 0 if not use_time_embedding else (2 if use_time_attenuation else 1)
+        self.set_mlp_precision(mlp_precision)
         if use_time_embedding:
             self.time_encoder = SinusoidalEncoder(1, 0, 4, True)
             self.time_encoder_feat = SinusoidalEncoderWithExp(1, 0, 4, True)
@@ -112,9 +114,18 @@ class DNGPradianceField(torch.nn.Module):
         self._desc: Optional[_lib.FieldDesc] = None
         self._desc_lock = __import__("threading").Lock()     # frames in flight share one field
 
+    def set_mlp_precision(self, mlp_precision: str) -> "DNGPradianceField":
+        """Arithmetic of the three MLPs (include/cednerf_hip.h): "f32" = exact fp32 MFMA chain, bit-identical
+        to the CPU oracle; "f16x2" = split-fp16 MFMA, fp32-grade results; "f16" = fp16 operands with fp32
+        accumulation, the precision class of the reference's tiny-cuda-nn networks (cednerf/model.py:200-222)."""
+        if mlp_precision not in _lib.MLP_PRECISIONS:
+            raise ValueError(f"mlp_precision must be one of {sorted(_lib.MLP_PRECISIONS)}, got {mlp_precision!r}")
+        self.mlp_precision = mlp_precision
+        return self
+
     # ---- parameter plumbing -------------------------------------------------------------------
     @classmethod
-    def from_params(cls, params: Dict, device="cuda") -> "DNGPradianceField":
+    def from_params(cls, params: Dict, device="cuda", mlp_precision: str = "f32") -> "DNGPradianceField":
         """Build from the plain-numpy parameter dict of ced_nerf_amd.synthetic.init_field_params."""
         h = params["hash"]
         table = torch.from_numpy(np.ascontiguousarray(h["table"]))
@@ -122,7 +133,7 @@ class DNGPradianceField(torch.nn.Module):
                 base_resolution=h["base_res"], n_levels=h["n_levels"], log2_hashmap_size=h["log2_hashmap_size"],
                 moving_step=params["moving_step"], use_div_offsets=params["use_div_offsets"],
                 use_time_embedding=params["time_mode"] != 0, use_time_attenuation=params["time_mode"] == 2,
-                hash_dtype=table.dtype, temporal_hash=h.get("temporal", False))
+                hash_dtype=table.dtype, temporal_hash=h.get("temporal", False), mlp_precision=mlp_precision)
         with torch.no_grad():
             f.hash_table.data = table
             for dst, src in ((f.xyz_wrap, params["xyz_wrap"]), (f.mlp_base, params["mlp_base"]),
@@ -159,7 +170,7 @@ class DNGPradianceField(torch.nn.Module):
     def _descriptor_locked(self) -> _lib.FieldDesc:
         ws = self._weights()
         key = (tuple((w.data_ptr(), w._version) for w in ws), self.hash_table.data_ptr(), str(self.hash_table.device),
-               self.aabb.data_ptr(), self.aabb._version)
+               self.aabb.data_ptr(), self.aabb._version, self.mlp_precision)
         if self._desc is not None and key == self._packed_key:
             return self._desc
         dev = self.hash_table.device
@@ -168,7 +179,8 @@ class DNGPradianceField(torch.nn.Module):
         blob = ops.pack_field_weights(self.use_div_offsets, self.time_mode,
                                       [w.detach().cpu().numpy() for w in self.xyz_wrap],
                                       [w.detach().cpu().numpy() for w in self.mlp_base],
-                                      [w.detach().cpu().numpy() for w in self.mlp_head])
+                                      [w.detach().cpu().numpy() for w in self.mlp_head],
+                                      _lib.MLP_PRECISIONS[self.mlp_precision])
         self._packed = torch.from_numpy(blob).to(dev)
         hd, _ = ops.make_hash_desc(self.hash_table.data, **self.hash_cfg)
         d = _lib.FieldDesc()
@@ -178,6 +190,7 @@ class DNGPradianceField(torch.nn.Module):
         d.moving_step = float(np.float32(self.MOVING_STEP))
         d.use_div_offsets = int(self.use_div_offsets)
         d.time_mode = int(self.time_mode)
+        d.mlp_precision = _lib.MLP_PRECISIONS[self.mlp_precision]
         d.packed_weights = self._packed.data_ptr()
         d.packed_floats = int(self._packed.numel())
         d.hash = hd

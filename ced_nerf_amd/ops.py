@@ -71,8 +71,10 @@ def make_hash_desc(table: torch.Tensor, base_res: int, max_res: int, n_levels: i
     return d, tabs
 
 
-def pack_field_weights(use_div_offsets: bool, time_mode: int, xyz_wrap, mlp_base, mlp_head) -> np.ndarray:
-    """Host: natural W[out][in] float32 arrays -> MFMA-fragment-order blob (ced_pack_field_weights)."""
+def pack_field_weights(use_div_offsets: bool, time_mode: int, xyz_wrap, mlp_base, mlp_head,
+                       mlp_precision: int = _lib.MLP_F32) -> np.ndarray:
+    """Host: natural W[out][in] float32 arrays -> MFMA-fragment-order blob (ced_pack_field_weights for the
+    fp32 kernel, ced_pack_field_weights_half for the f16x2 / f16 kernels; the latter returns uint32 words)."""
     L = _lib.lib()
     mats = [np.ascontiguousarray(np.asarray(w, np.float32)) for w in list(xyz_wrap) + list(mlp_base) + list(mlp_head)]
     base_in = 41 if time_mode else 32
@@ -81,6 +83,15 @@ def pack_field_weights(use_div_offsets: bool, time_mode: int, xyz_wrap, mlp_base
     got = [m.shape for m in mats]
     if got != want:
         raise ValueError(f"weight shapes {got} do not match the DNGPradianceField layout {want}")
+    if mlp_precision != _lib.MLP_F32:
+        n = int(L.ced_packed_weight_words(int(use_div_offsets), int(time_mode), int(mlp_precision)))
+        if n <= 0:
+            raise ValueError(f"mlp_precision={mlp_precision}")
+        out = np.zeros((n,), np.uint32)
+        rc = L.ced_pack_field_weights_half(int(use_div_offsets), int(time_mode), int(mlp_precision),
+                                           *[m.ctypes.data_as(C.c_void_p) for m in mats], out.ctypes.data_as(C.c_void_p))
+        _lib.check(rc, "pack_field_weights_half")
+        return out
     n = int(L.ced_packed_weight_floats(int(use_div_offsets), int(time_mode)))
     out = np.zeros((n,), np.float32)
     rc = L.ced_pack_field_weights(int(use_div_offsets), int(time_mode),

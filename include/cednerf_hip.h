@@ -63,9 +63,9 @@ typedef struct ced_field_desc {
     float moving_step;           /* model.py:151, train_real.py:104,136,169 */
     int32_t use_div_offsets;     /* model.py:356-358 */
     int32_t time_mode;           /* 0 none, 1 SinusoidalEncoder, 2 SinusoidalEncoderWithExp (model.py:386-396) */
-    int32_t reserved;
-    const float *packed_weights; /* device: blob written by ced_pack_field_weights */
-    uint64_t packed_floats;
+    int32_t mlp_precision;       /* CED_MLP_F32 / CED_MLP_F16X2 / CED_MLP_F16: arithmetic of the three MLPs (below) */
+    const void *packed_weights;  /* device: blob written by ced_pack_field_weights[_half] for that precision */
+    uint64_t packed_floats;      /* its size in 32-bit words: ced_packed_weight_words() */
     ced_hash_desc hash;
 } ced_field_desc;
 
@@ -78,7 +78,18 @@ const char *ced_last_error_string(void);
  * brick mask proves nothing occupied lies ahead, 0 walks every cell.  Results are identical. */
 int ced_set_option(const char *key, int value);
 
-/* Number of floats in the packed (MFMA-fragment-order) weight blob. */
+/* Arithmetic of xyz_wrap / mlp_base / mlp_head (everything else is fp32 in every mode):
+ *   CED_MLP_F32    v_mfma_f32_16x16x4_f32, an ascending-k fp32 FMA chain: bit-identical to the CPU oracle.
+ *   CED_MLP_F16X2  every operand split into two fp16 numbers (22 significant bits), three
+ *                  v_mfma_f32_16x16x32_f16 per product block, fp32 accumulation: fp32-grade results.
+ *   CED_MLP_F16    operands rounded to fp16, fp32 accumulation: the precision class of the reference's
+ *                  tiny-cuda-nn FullyFusedMLP (cednerf/model.py:200-222,280-309).
+ * The half modes assume |weights|, |activations| <= 65504 (activations saturate there), like tcnn. */
+#define CED_MLP_F32 0
+#define CED_MLP_F16X2 1
+#define CED_MLP_F16 2
+
+/* Number of floats in the packed (MFMA-fragment-order) fp32 weight blob. */
 int64_t ced_packed_weight_floats(int use_div_offsets, int time_mode);
 
 /* HOST function: reorders natural-layout weights W[out][in] (row-major, host pointers) into the
@@ -91,6 +102,16 @@ int ced_pack_field_weights(int use_div_offsets, int time_mode,
                            const float *b_w0, const float *b_w1,
                            const float *h_w0, const float *h_w1, const float *h_w2,
                            float *out);
+
+/* The same for the half-precision MLP modes: size of the blob in 32-bit words for any mlp_precision, and
+ * the HOST packer for CED_MLP_F16X2 / CED_MLP_F16 (weights are rounded to fp16 here; F16X2 also stores the
+ * fp16 remainders). */
+int64_t ced_packed_weight_words(int use_div_offsets, int time_mode, int mlp_precision);
+int ced_pack_field_weights_half(int use_div_offsets, int time_mode, int mlp_precision,
+                                const float *m_w0, const float *m_w1, const float *m_w2, const float *m_w3,
+                                const float *b_w0, const float *b_w1,
+                                const float *h_w0, const float *h_w1, const float *h_w2,
+                                void *out);
 
 /* nerfacc.ray_aabb_intersect(rays_o, rays_d, aabbs, near_plane, far_plane, miss_value)
  * -- call site cednerf/utils.py:215.  Outputs [n_rays, n_aabbs]. */

@@ -490,7 +490,33 @@ typedef struct {
     const float *b_w0, *b_w1;                 /* 64xbase_in, 16x64 */
     const float *h_w0, *h_w1, *h_w2;          /* 64x19, 64x64, 3x64 */
     ced_o_hash_t hash;
+    int32_t mlp_half;              /* 1: the fp16-operand / fp32-accumulate MLP class of tcnn's FullyFusedMLP
+                                      (SURVEY A.8): every layer input is rounded to fp16 (saturating at 65504);
+                                      the caller passes weights already rounded to fp16.  0: plain fp32. */
+    int32_t reserved;
 } ced_o_field_t;
+
+/* x rounded to the nearest fp16 value (ties to even, subnormals kept), saturating at +-65504 */
+static float round_f16(float x)
+{
+    if (x != x) return x;
+    float a = fabsf(x), r;
+    if (a >= 65504.0f) r = 65504.0f;
+    else if (a < 6.103515625e-05f) r = rintf(a * 16777216.0f) / 16777216.0f;
+    else {
+        int e;
+        (void)frexpf(a, &e);                       /* a = m * 2^e, m in [0.5, 1): 11 significant bits -> ulp 2^(e-11) */
+        float ulp = ldexpf(1.0f, e - 11);
+        r = rintf(a / ulp) * ulp;
+    }
+    return copysignf(r, x);
+}
+
+/* exported for the oracle's own tests (checked against numpy's float16 conversion) */
+void ced_o_round_f16(int64_t n, const float *x, float *y)
+{
+    for (int64_t i = 0; i < n; ++i) y[i] = round_f16(x[i]);
+}
 
 static inline float dotf(const float *w, const float *x, int n)
 {
@@ -498,8 +524,14 @@ static inline float dotf(const float *w, const float *x, int n)
     for (int k = 0; k < n; ++k) acc = fmaf(w[k], x[k], acc);
     return acc;
 }
-static void dense(const float *w, int n_out, int n_in, const float *x, float *y, int relu)
+static void dense(const float *w, int n_out, int n_in, const float *x_in, float *y, int relu, int half)
 {
+    float xr[64];
+    const float *x = x_in;
+    if (half) {
+        for (int k = 0; k < n_in; ++k) xr[k] = round_f16(x_in[k]);
+        x = xr;
+    }
     for (int o = 0; o < n_out; ++o) {
         float v = dotf(w + (int64_t)o * n_in, x, n_in);
         y[o] = relu ? (v > 0.0f ? v : 0.0f) : v;
@@ -519,11 +551,11 @@ static void field_one(const ced_o_field_t *f, const float *pos, float t, const f
             enc[d * 8 + k * 2] = ced_o_sinpi_phase(y, 0);
             enc[d * 8 + k * 2 + 1] = ced_o_sinpi_phase(y, 1);
         }
-    dense(f->m_w0, 64, 32, enc, h0, 1);
-    dense(f->m_w1, 64, 64, h0, h1, 1);
-    dense(f->m_w2, 64, 64, h1, h0, 1);
+    dense(f->m_w0, 64, 32, enc, h0, 1, f->mlp_half);
+    dense(f->m_w1, 64, 64, h0, h1, 1, f->mlp_half);
+    dense(f->m_w2, 64, 64, h1, h0, 1, f->mlp_half);
     int n_mo = f->use_div_offsets ? 6 : 3;
-    dense(f->m_w3, n_mo, 64, h0, mo, 0);
+    dense(f->m_w3, n_mo, 64, h0, mo, 0, f->mlp_half);
     float move[3], xn[3];
     int sel = 1;
     for (int a = 0; a < 3; ++a) {                                 /* model.py:356-363 */
@@ -545,8 +577,8 @@ static void field_one(const ced_o_field_t *f, const float *pos, float t, const f
         float mn = sqrtf((move[0] * move[0] + move[1] * move[1]) + move[2] * move[2]);
         ced_o_time_encode(t, mn, f->time_mode == 2, bin + 32);
     }
-    dense(f->b_w0, 64, f->base_in, bin, h0, 1);
-    dense(f->b_w1, 16, 64, h0, bout, 0);
+    dense(f->b_w0, 64, f->base_in, bin, h0, 1, f->mlp_half);
+    dense(f->b_w1, 16, 64, h0, bout, 0, f->mlp_half);
     float s = ced_o_expf(bout[0] - 1.0f);                         /* model.py:105,414-417 */
     if (!sel) s = 0.0f;
     if (sigma) *sigma = s;
@@ -566,9 +598,9 @@ static void field_one(const ced_o_field_t *f, const float *pos, float t, const f
         hin[3] = -0.48860251190291987f * v[0];
         for (int i = 0; i < 15; ++i) hin[4 + i] = bout[1 + i];
         float o3[3];
-        dense(f->h_w0, 64, 19, hin, h0, 1);
-        dense(f->h_w1, 64, 64, h0, h1, 1);
-        dense(f->h_w2, 3, 64, h1, o3, 0);
+        dense(f->h_w0, 64, 19, hin, h0, 1, f->mlp_half);
+        dense(f->h_w1, 64, 64, h0, h1, 1, f->mlp_half);
+        dense(f->h_w2, 3, 64, h1, o3, 0, f->mlp_half);
         for (int a = 0; a < 3; ++a) rgb[a] = 1.0f / (1.0f + ced_o_expf(-o3[a]));   /* sigmoid */
     }
 }

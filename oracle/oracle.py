@@ -47,7 +47,7 @@ class _FieldT(C.Structure):
         ("m_w0", C.c_void_p), ("m_w1", C.c_void_p), ("m_w2", C.c_void_p), ("m_w3", C.c_void_p),
         ("b_w0", C.c_void_p), ("b_w1", C.c_void_p),
         ("h_w0", C.c_void_p), ("h_w1", C.c_void_p), ("h_w2", C.c_void_p),
-        ("hash", _HashT),
+        ("hash", _HashT), ("mlp_half", C.c_int32), ("reserved", C.c_int32),
     ]
 
 
@@ -79,6 +79,14 @@ def _f32(a) -> np.ndarray:
     return np.ascontiguousarray(np.asarray(a, dtype=np.float32))
 
 
+def round_f16(x: np.ndarray) -> np.ndarray:
+    """The C oracle's fp32 -> fp16-grid rounding (ties to even, saturating at +-65504)."""
+    x = _f32(x)
+    y = np.empty_like(x)
+    lib().ced_o_round_f16(C.c_int64(x.size), _p(x), _p(y))
+    return y
+
+
 # ---------------------------------------------------------------------------------------------
 # hash-grid level geometry (host, float64): hash_encoder_half.py:12-35 (align_to, res/scale),
 # :268-292 (offsets, sizes, first hashed level); SURVEY A.6.
@@ -107,7 +115,9 @@ def hash_levels(base_res: int = 16, max_res: int = 1024, n_levels: int = 16, log
 class OracleField:
     """DNGPradianceField (cednerf/model.py:97-488) evaluated by the C oracle."""
 
-    def __init__(self, params: Dict):
+    def __init__(self, params: Dict, mlp_half: bool = False):
+        """mlp_half: the fp16-operand / fp32-accumulate MLP class (tcnn FullyFusedMLP): weights are
+        rounded to fp16 here, layer inputs inside the C code."""
         self.p = params
         h = params["hash"]
         self.levels = hash_levels(h["base_res"], h["max_res"], h["n_levels"], h["log2_hashmap_size"])
@@ -139,9 +149,11 @@ class OracleField:
         ft.use_div_offsets = int(bool(params["use_div_offsets"]))
         ft.time_mode = int(params["time_mode"])
         ft.base_in = 41 if ft.time_mode else 32
-        m = [_f32(w) for w in params["xyz_wrap"]]
-        b = [_f32(w) for w in params["mlp_base"]]
-        hd = [_f32(w) for w in params["mlp_head"]]
+        rw = (lambda w: _f32(_f32(w).astype(np.float16))) if mlp_half else _f32
+        ft.mlp_half = int(bool(mlp_half))
+        m = [rw(w) for w in params["xyz_wrap"]]
+        b = [rw(w) for w in params["mlp_base"]]
+        hd = [rw(w) for w in params["mlp_head"]]
         assert m[0].shape == (64, 32) and m[1].shape == (64, 64) and m[2].shape == (64, 64)
         assert m[3].shape == (6 if ft.use_div_offsets else 3, 64)
         assert b[0].shape == (64, ft.base_in) and b[1].shape == (16, 64)

@@ -262,3 +262,19 @@ def test_empty_and_ragged_inputs(oracle):
     assert out[3] == 0 and np.all(out[0] == 1.0) and np.all(out[1] == 0) and np.all(out[2] == 0)
     out = oracle.render_image(f, empty, sc["origins"], sc["viewdirs"], timestamps=sc["timestamps"], **sc["render"])
     assert out[3] == 0 and np.all(out[0] == 1.0)
+
+
+def test_oracle_fp16_rounding_matches_numpy(oracle):
+    """The fp16-operand MLP mode of the oracle rests on this rounding: check it against numpy's
+    float16 conversion (ties to even, subnormals), plus the saturation at 65504."""
+    rng = np.random.default_rng(1)
+    x = (rng.normal(size=300000) * 10.0 ** rng.uniform(-9, 5, 300000)).astype(np.float32)
+    x = np.concatenate([x, np.float32([0, 65504, 65519.9, 6.1e-5, 6.103515625e-05, 5.96e-8, 2.98e-8, 2.9802322e-8, 3e-8,
+                                       8.9e-8, 1.0 + 2.0 ** -11, 1.0 + 3 * 2.0 ** -11])])
+    y = oracle.round_f16(x)
+    with np.errstate(over="ignore"):
+        ref = x.astype(np.float16).astype(np.float32)
+    ref = np.where(np.isinf(ref), np.sign(x) * np.float32(65504), ref)
+    assert np.array_equal(y, ref)
+    assert np.array_equal(oracle.round_f16(np.float32([65520, 1e9, -1e9])), np.float32([65504, 65504, -65504]))
+    assert np.signbit(oracle.round_f16(np.float32([-0.0]))[0])

@@ -26,7 +26,33 @@ t0, t1, ri, packed, _ = march_packed(o, d, est.binaries, est.aabbs, near, far, c
 ts = T(sc["timestamps"]).reshape(-1)
 N = t0.shape[0]
 print("samples", N)
+prec = os.environ.get("PRECISION", "f32")
+ref = None
+if prec != "f32":
+    ref = ops.field_forward_rays(f._descriptor(), o, d, ri, t0, t1, ts, False, True)
+    ref = (ref[0].clone(), ref[1].clone())
+    f.set_mlp_precision(prec)
 res = {}
+for hv in [int(v) for v in os.environ.get("HALF_VARIANTS", "0").split(",")]:
+    if prec == "f32":
+        continue
+    _lib.check(_lib.lib().ced_set_option(b"half_variant", hv))
+    for _ in range(2):
+        out = ops.field_forward_rays(f._descriptor(), o, d, ri, t0, t1, ts, False, True)
+    torch.cuda.synchronize()
+    e0 = torch.cuda.Event(enable_timing=True); e1 = torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(5):
+        out = ops.field_forward_rays(f._descriptor(), o, d, ri, t0, t1, ts, False, True)
+    e1.record(); torch.cuda.synchronize()
+    ms = e0.elapsed_time(e1) / 5
+    drgb = (out[0] - ref[0]).abs().max().item()
+    rel = ((out[1] - ref[1]).abs() / ref[1].abs().clamp_min(1e-6)).max().item()
+    dsig = (out[1] - ref[1]).abs().max().item()
+    print(f"precision {prec} half_variant {hv}: {ms:.3f} ms -> {N/ms*1e3/1e9:.3f} Gsamples/s; vs f32: max|drgb| {drgb:.3e}, "
+          f"max|dsigma| {dsig:.3e} (max sigma {ref[1].max().item():.3e}), max rel dsigma {rel:.3e}")
+if prec != "f32":
+    sys.exit(0)
 for variant in [int(v) for v in os.environ.get('VARIANTS', '2').split(',')]:
     _lib.check(_lib.lib().ced_set_option(b"field_variant", variant))
     for stg in [int(v) for v in os.environ.get('STAGGER', '0').split(',')]:
