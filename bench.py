@@ -24,6 +24,7 @@ ALG_BYTES_PER_SAMPLE_F16 = 560.0
 ALG_FLOPS_PER_SAMPLE = 38.0e3         # unpadded MLP flops per sample
 PEAK_HBM_GBS = 8000.0                 # MI355X_MICROARCH.md: HBM3E 8 TB/s
 PEAK_F32_MFMA_TFLOPS = 157.3          # MI355X_MICROARCH.md: f32-input MFMA dense peak
+PEAK_F16_MFMA_TFLOPS = 2500.0         # MI355X_MICROARCH.md: f16/bf16 MFMA dense peak
 
 
 def parse():
@@ -35,6 +36,13 @@ def parse():
     ap.add_argument("--height", type=int, default=800)
     ap.add_argument("--scene", default="dnerf", choices=["dnerf", "hypernerf", "dynerf"])
     ap.add_argument("--table-dtype", default="f32", choices=["f32", "f16"])
+    ap.add_argument("--also", default="f16x2,f16",
+                    help="comma list of further --mlp-precision modes to time briefly after the main measurement "
+                         "(reported under other_mlp_precisions; empty string: none)")
+    ap.add_argument("--mlp-precision", default="f32", choices=["f32", "f16x2", "f16"],
+                    help="arithmetic of the three MLPs (include/cednerf_hip.h CED_MLP_*): f32 = exact fp32 MFMA chain, "
+                         "bit-identical to the CPU oracle; f16x2 = split-fp16 MFMA with fp32 accumulation, fp32-grade "
+                         "(<= 1e-4 on pixels, same sample counts); f16 = fp16 operands, the reference's tcnn class")
     ap.add_argument("--pmc-json", default=os.path.join(ROOT, "profiles", "r01_pmc_field.json"),
                     help="per-launch HBM traffic of the field kernel from the rocprofv3 --pmc passes (tools/pmc_summary.py)")
     ap.add_argument("--regime", default="trained")
@@ -131,7 +139,7 @@ def main():
         return {"origins": o, "viewdirs": d}
 
     frames = [frame_rays(f) for f in range(n_frames)]
-    field = DNGPradianceField.from_params(sc["params"], dev).eval()
+    field = DNGPradianceField.from_params(sc["params"], dev, mlp_precision=args.mlp_precision).eval()
     field._descriptor()
     est = OccGridEstimator(cfg["aabb"], cfg["grid_resolution"], cfg["grid_levels"]).to(dev)
     est.set_binaries(T(sc["binaries"]))
@@ -203,6 +211,33 @@ def main():
         dt = float(tmax[0]); samples_total = float(tsum[1])
     else:
         samples_total = float(samples_local)
+    # the same step in the other MLP arithmetic modes (shorter run; same barrier / max-over-ranks discipline)
+    others = {}
+    for prec in [p for p in args.also.split(",") if p and p != args.mlp_precision]:
+        field.set_mlp_precision(prec)
+        field._descriptor()
+        step()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+        k = max(1, min(args.steps, 6))
+        t_a = time.perf_counter()
+        s_loc = 0
+        for _ in range(k):
+            s_loc += step()["local_samples"]
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        tt2 = torch.tensor([time.perf_counter() - t_a, float(s_loc)], device=dev, dtype=torch.float64)
+        if world > 1:
+            t2max = tt2.clone(); dist.all_reduce(t2max, op=dist.ReduceOp.MAX)
+            t2sum = tt2.clone(); dist.all_reduce(t2sum, op=dist.ReduceOp.SUM)
+            tt2 = torch.stack([t2max[0], t2sum[1]])
+        others[prec] = {"value": float(tt2[1]) / float(tt2[0]), "unit": "samples/s", "steps": k,
+                        "ms_per_frame": 1e3 * float(tt2[0]) / k / lanes,
+                        "rays_per_sec": n_frames * args.width * args.height * k / float(tt2[0])}
+    field.set_mlp_precision(args.mlp_precision)
+    field._descriptor()
     if rank != 0:
         if world > 1:
             dist.destroy_process_group()
@@ -225,7 +260,9 @@ def main():
         "metric": "samples_per_sec (render_image_test, 800x800 D-NeRF lego-shaped synthetic)",
         "value": samples_total / dt, "unit": "samples/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": 1e3 * dt / args.steps, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-        "dtype": "f32", "data": "synthetic",
+        "dtype": {"f32": "f32", "f16x2": "f32 (MLP GEMMs: split-fp16 MFMA, 22-bit operands, fp32 accumulate)",
+                  "f16": "f16 MLP operands, fp32 accumulate; rest f32"}[args.mlp_precision],
+        "mlp_precision": args.mlp_precision, "data": "synthetic",
         "rays_per_sec": n_rays_step * args.steps / dt,
         "ms_per_frame": 1e3 * dt / args.steps / lanes, "single_frame_latency_ms": single_ms,
         "samples_per_ray": samples_total / (n_rays_step * args.steps),
@@ -248,33 +285,56 @@ def main():
         tflops = samples_per_launch * ALG_FLOPS_PER_SAMPLE / (avg_ms * 1e-3) / 1e12
         gbs = samples_per_launch * (ALG_BYTES_PER_SAMPLE_F16 if fp16 else ALG_BYTES_PER_SAMPLE_F32) / (avg_ms * 1e-3) / 1e9
         traffic = None
+        exact_kernel = args.mlp_precision == "f32"
         if args.scene == "dnerf" and not fp16 and os.path.exists(args.pmc_json):
             try:        # HBM bytes per launch from the committed PMC passes of this same workload
                 pj = json.load(open(args.pmc_json))
-                k = [v for n, v in pj.items() if n.startswith("void ced::field_kernel")][0]
+                kpat = "void ced::field_kernel" if exact_kernel else "void ced::field_half_kernel"
+                k = [v for n, v in pj.items() if n.startswith(kpat)][0]
                 traffic = k["fetch_bytes_per_launch"] + k["write_bytes_per_launch"]
             except Exception:
                 traffic = None
+        # Which roofline bounds the field kernel depends on the MLP arithmetic.  f32: the exact fp32 MFMA chain is
+        # matrix-bound (fp32 MFMA peak).  f16x2 / f16: the GEMMs shrink to a few % of the f16 MFMA peak and the
+        # kernel is bound by the hash lookup (SURVEY 8d algorithmic bytes per sample against HBM peak -- the
+        # north-star's "HBM roofline on the hash lookup"); the other bound is reported beside it.
+        exact = args.mlp_precision == "f32"
+        mfma_peak = PEAK_F32_MFMA_TFLOPS if exact else PEAK_F16_MFMA_TFLOPS
+        alg_bytes = ALG_BYTES_PER_SAMPLE_F16 if fp16 else ALG_BYTES_PER_SAMPLE_F32
+        kname = "field_kernel" if exact else "field_half_kernel"
+        common = {"avg_launch_ms": avg_ms, "launches": fk["launches"], "samples_per_launch": samples_per_launch,
+                  "avg_launch_ms_raw": raw_avg_ms,
+                  "field_busy_over_wall": busy_ms / (1e3 * dt * min(args.steps, 24) / args.steps),
+                  "note": "%d frame(s) in flight: avg_launch_ms = (time with a field kernel executing) / launches; "
+                          "avg_launch_ms_raw = mean begin->end of a launch (overlapping launches share the chip; this is "
+                          "what rocprofv3 --stats lists); roofline_single_frame = the kernel with one frame in flight" % lanes}
+        r_mfma = {"kernel": f"{kname} (fused DNGPradianceField forward, mlp_precision={args.mlp_precision})",
+                  "bound": "mfma", "achieved": tflops, "peak": mfma_peak, "unit": "TFLOP/s", "frac": tflops / mfma_peak,
+                  "traffic": traffic, "alg_flops_per_sample": ALG_FLOPS_PER_SAMPLE}
+        r_hbm = {"kernel": r_mfma["kernel"], "bound": "hbm", "achieved": gbs, "peak": PEAK_HBM_GBS, "unit": "GB/s",
+                 "frac": gbs / PEAK_HBM_GBS, "traffic": traffic, "alg_bytes_per_sample": alg_bytes}
         # uncontended figure: the same kernel while only ONE frame is in flight (measured after the timed region)
         if single_field is not None and single_field["launches"] > 0:
             s_ms = single_field["ms"] / single_field["launches"]
-            s_tf = single_field["units"] / single_field["launches"] * ALG_FLOPS_PER_SAMPLE / (s_ms * 1e-3) / 1e12
-            line["roofline_single_frame"] = {"bound": "mfma", "achieved": s_tf, "peak": PEAK_F32_MFMA_TFLOPS,
-                                             "unit": "TFLOP/s", "frac": s_tf / PEAK_F32_MFMA_TFLOPS,
-                                             "avg_launch_ms": s_ms, "launches": single_field["launches"]}
-        line["roofline"] = {"kernel": "field_kernel (fused DNGPradianceField forward)", "bound": "mfma",
-                            "achieved": tflops, "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
-                            "frac": tflops / PEAK_F32_MFMA_TFLOPS, "traffic": traffic,
-                            "avg_launch_ms": avg_ms, "launches": fk["launches"],
-                            "samples_per_launch": samples_per_launch,
-                            "avg_launch_ms_raw": raw_avg_ms, "field_busy_over_wall": busy_ms / (1e3 * dt * min(args.steps, 24) / args.steps),
-                            "note": "%d frame(s) in flight: avg_launch_ms = (time with a field kernel executing) / "
-                                    "launches; avg_launch_ms_raw = mean begin->end of a launch (overlapping launches "
-                                    "share the chip; this is what rocprofv3 --stats lists); roofline_single_frame = "
-                                    "the kernel with one frame in flight" % lanes}
-        line["roofline_hbm"] = {"bound": "hbm", "achieved": gbs, "peak": PEAK_HBM_GBS, "unit": "GB/s",
-                                "frac": gbs / PEAK_HBM_GBS, "traffic": traffic}
+            s_spl = single_field["units"] / single_field["launches"]
+            s_tf = s_spl * ALG_FLOPS_PER_SAMPLE / (s_ms * 1e-3) / 1e12
+            s_gbs = s_spl * alg_bytes / (s_ms * 1e-3) / 1e9
+            line["roofline_single_frame"] = (
+                {"bound": "mfma", "achieved": s_tf, "peak": mfma_peak, "unit": "TFLOP/s", "frac": s_tf / mfma_peak} if exact else
+                {"bound": "hbm", "achieved": s_gbs, "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": s_gbs / PEAK_HBM_GBS})
+            line["roofline_single_frame"].update({"avg_launch_ms": s_ms, "launches": single_field["launches"]})
+        line["roofline"] = dict(r_mfma if exact else r_hbm, **common)
+        line["roofline_hbm" if exact else "roofline_mfma"] = r_hbm if exact else r_mfma
         line["kernel_ms_per_step"] = {k: v["ms"] / min(args.steps, 24) for k, v in prof.items()}
+    if others:
+        notes = {"f16x2": "split-fp16 MFMA MLPs, fp32 accumulate: pixels within 1e-4 of the oracle, sample count within 1e-5 "
+                          "relative (early-stop decisions at rounding distance from the threshold may flip)",
+                 "f16": "fp16-operand MLPs (the reference's tcnn class; BASELINE config 5 with --table-dtype f16): parity "
+                        "against the oracle's fp16-operand mode, tolerance in tests/test_gpu_parity.py",
+                 "f32": "exact fp32 MFMA chain: bit-identical to the oracle"}
+        for k_, v_ in others.items():
+            v_["parity"] = notes[k_]
+        line["other_mlp_precisions"] = others
     if not args.no_cpu_baseline:
         line["cpu_baseline"] = cpu_baseline(sc, args)
         if args.torch_stride > 0:

@@ -2,7 +2,7 @@
 // field.hip; selected by ced_field_desc.mlp_precision):
 //
 //   CED_MLP_F16X2 (1): every MLP operand is split into two fp16 numbers, x = hi + lo (22 significant
-//       bits), and each product block is three v_mfma_f32_16x16x32_f16 (hi*hi + hi*lo + lo*hi) with
+//       bits), and each product block is three fp16 MFMA blocks (hi*hi + hi*lo + lo*hi) with
 //       fp32 accumulation -- fp32-grade results (~1e-6 relative) at a fraction of the fp32-MFMA time.
 //   CED_MLP_F16   (2): operands rounded to fp16, fp32 accumulation: the precision class of the
 //       reference's tiny-cuda-nn FullyFusedMLP (cednerf/model.py:200-222,280-309) and of
@@ -11,7 +11,7 @@
 // Everything outside the GEMMs (Frequency / SH / time encodings, hash-grid gather and interpolation,
 // trunc_exp, sigmoid, the selector) is the same fp32 code as the exact kernel (field_device.hpp).
 //
-// Geometry: D^T = W * X^T as in field.hip, but K = 32 per MFMA: lane (g = lane>>4, c = lane&15) supplies
+// Geometry: D^T = W * X^T as in field.hip, but K = 32 per product block (mfma_k32, field_half_device.hpp): lane (g = lane>>4, c = lane&15) supplies
 // inputs 32ks + 8g + e (e = 0..7, four packed VGPRs) of sample c, and receives accumulator rows 4g + r.
 // The host packs the weight rows of every 64-wide hidden layer so that accumulator row 16nb + 4g + r
 // holds neuron 32(nb>>1) + 8g + 4(nb&1) + r: the eight values a lane needs as operand of k-step ks are
@@ -25,12 +25,9 @@
 #include "ced_common.hpp"
 #include "field_args.hpp"
 #include "field_device.hpp"
+#include "field_half_device.hpp"
 
 namespace ced {
-
-typedef _Float16 h8 __attribute__((ext_vector_type(8)));
-
-constexpr int kFragHalves = 512;      // one (nb, ks) A fragment: 64 lanes x 8 halves
 
 // packed blob, in fragments: layer l = [nb][ks] fragments; a second plane of the same shape holds the
 // low parts in F16X2 mode
@@ -47,86 +44,6 @@ template <bool TE> struct HalfBlob {
     static constexpr int H2 = H1 + 4 * 2;
     static constexpr int FRAGS = H2 + 1 * 2;       // 42 / 46
 };
-
-// accumulator row -> neuron of a 64-wide hidden layer (see the header comment)
-__host__ __device__ constexpr int half_hidden_neuron(int p)
-{
-    const int nb = p >> 4, g = (p >> 2) & 3, r = p & 3;
-    return 32 * (nb >> 1) + 8 * g + 4 * (nb & 1) + r;
-}
-// mlp_base output: row p < 15 is geometry feature p (neuron 1 + p), row 15 the raw density (neuron 0)
-__host__ __device__ constexpr int half_base_out_neuron(int p) { return p < 15 ? p + 1 : 0; }
-
-constexpr float kHalfMax = 65504.0f;
-
-#ifndef CED_HALF_MFMA_GUARD
-#define CED_HALF_MFMA_GUARD 1
-#endif
-
-// eight fp32 values -> packed fp16 operand (and the fp16 remainder in F16X2 mode)
-template <bool SPLIT> __device__ __forceinline__ void to_half8(const float (&v)[8], h8 &hi, h8 &lo)
-{
-#pragma unroll
-    for (int e = 0; e < 8; ++e) {
-        const _Float16 h = (_Float16)v[e];
-        hi[e] = h;
-        if constexpr (SPLIT) lo[e] = (_Float16)(v[e] - (float)h);
-    }
-}
-
-template <int KS, int NB, int NT, bool SPLIT>
-__device__ __forceinline__ void mlp_layer_h(const _Float16 *__restrict__ whi, const _Float16 *__restrict__ wlo, int lane,
-                                            const h8 (&Bh)[NT][2], const h8 (&Bl)[NT][2], f4 (&D)[NT][4])
-{
-#pragma unroll
-    for (int nb = 0; nb < NB; ++nb) {
-        f4 acc[NT];
-#pragma unroll
-        for (int j = 0; j < NT; ++j) acc[j] = f4{ 0.0f, 0.0f, 0.0f, 0.0f };
-#pragma unroll
-        for (int ks = 0; ks < KS; ++ks) {
-            const h8 ah = *reinterpret_cast<const h8 *>(whi + ((nb * KS + ks) * 64 + lane) * 8);
-            if constexpr (SPLIT) {
-                const h8 al = *reinterpret_cast<const h8 *>(wlo + ((nb * KS + ks) * 64 + lane) * 8);
-#pragma unroll
-                for (int j = 0; j < NT; ++j) acc[j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(al, Bh[j][ks], acc[j], 0, 0, 0);
-#pragma unroll
-                for (int j = 0; j < NT; ++j) acc[j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, Bl[j][ks], acc[j], 0, 0, 0);
-            }
-#pragma unroll
-            for (int j = 0; j < NT; ++j) acc[j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, Bh[j][ks], acc[j], 0, 0, 0);
-            // Operand guard (measured on MI355X, ROCm 7.2): without it hipcc interleaves the fp32->fp16
-            // conversions of the NEXT operands with these MFMAs and hands them the A/B registers of the MFMA it
-            // has just issued (their last use).  With 3 waves per SIMD ~0.2 % of the 16-sample tiles then came out
-            // wrong, non-reproducibly, always the tile of the group's last MFMA: the 4-VGPR operands of
-            // v_mfma_f32_16x16x32_f16 are still being read when the next VALU result lands in them.  Fencing the
-            // scheduler around each group plus one s_nop removes every bad tile (15 M-sample launches,
-            // tests/test_gpu_parity.py::test_field_forward_large_persistent_launch) at no measurable cost.
-            __builtin_amdgcn_sched_barrier(0);
-            asm volatile("s_nop %0" ::"n"(CED_HALF_MFMA_GUARD));
-            __builtin_amdgcn_sched_barrier(0);
-        }
-#pragma unroll
-        for (int j = 0; j < NT; ++j) D[j][nb] = acc[j];
-    }
-}
-
-// ReLU + saturation to the fp16 range (one v_med3_f32), then the accumulator registers become the
-// next layer's operand: k-step ks takes D[2ks][0..3], D[2ks+1][0..3].
-template <int NT, bool SPLIT>
-__device__ __forceinline__ void to_operand_h(const f4 (&D)[NT][4], h8 (&Bh)[NT][2], h8 (&Bl)[NT][2])
-{
-#pragma unroll
-    for (int j = 0; j < NT; ++j) {
-#pragma unroll
-        for (int ks = 0; ks < 2; ++ks) {
-            float v[8];
-#pragma unroll
-            for (int e = 0; e < 8; ++e) v[e] = __builtin_amdgcn_fmed3f(D[j][2 * ks + (e >> 2)][e & 3], 0.0f, kHalfMax);
-            to_half8<SPLIT>(v, Bh[j][ks], Bl[j][ks]);
-        }
-    }
-}
 
 template <bool TE, bool F16, bool TEMPORAL, bool SPLIT, int NT, int THREADS>
 __global__ __launch_bounds__(THREADS) void field_half_kernel(FieldArgs A)
@@ -357,6 +274,38 @@ __global__ __launch_bounds__(THREADS) void field_half_kernel(FieldArgs A)
     }
 }
 
+// Host: one layer into 16x16x32 A-fragment order.  Element (accumulator row p, operand position k) goes to
+// fragment [frag + (p/16)*ks + k/32], lane 16*((k%32)/8) + p%16, half k%8; row_map says which neuron row p
+// computes, col_map which input of the layer sits at position k (header comment of this file).
+void pack_half_layer(const float *w, int n_out, int n_in, int nb, int ks, int frag, int row_map, int col_map,
+                     _Float16 *hi, _Float16 *lo)
+{
+    for (int p = 0; p < nb * 16; ++p) {
+        int neuron = p;
+        if (row_map == HALF_ROW_HIDDEN) neuron = half_hidden_neuron(p);
+        else if (row_map == HALF_ROW_BASE_OUT) neuron = half_base_out_neuron(p);
+        if (neuron >= n_out) continue;
+        for (int k = 0; k < ks * 32; ++k) {
+            const int g = (k % 32) / 8, e = k % 8;
+            int in = k;
+            if (col_map == HALF_COL_HASH) {
+                if (k < 32) in = 2 * (4 * (e >> 1) + g) + (e & 1);          // level 4i + g, feature f at e = 2i + f
+                else in = (e < 3 && 4 * e + g <= 8) ? 32 + 4 * e + g : -1;   // time feature 4e + g
+            } else if (col_map == HALF_COL_HEAD) {
+                if (e == 0) in = g;                                          // SH component g
+                else if (e <= 4 && 4 * g + e - 1 < 15) in = 4 + 4 * g + e - 1;   // geometry feature 4g + e - 1
+                else in = -1;
+            }
+            if (in < 0 || in >= n_in) continue;
+            const float v = w[(int64_t)neuron * n_in + in];
+            const _Float16 h = (_Float16)v;
+            const int64_t idx = ((int64_t)(frag + (p / 16) * ks + k / 32) * 64 + 16 * g + (p % 16)) * 8 + e;
+            hi[idx] = h;
+            if (lo) lo[idx] = (_Float16)(v - (float)h);
+        }
+    }
+}
+
 static int g_half_variant = [] { const char *e = getenv("CED_HALF_VARIANT"); return e ? atoi(e) : 0; }();
 void set_half_variant(int v) { g_half_variant = v; }
 
@@ -403,6 +352,7 @@ int launch_field_half(FieldArgs &A, int time_mode, int precision, void *stream)
 extern "C" int64_t ced_packed_weight_words(int use_div_offsets, int time_mode, int mlp_precision)
 {
     if (mlp_precision == CED_MLP_F32) return ced_packed_weight_floats(use_div_offsets, time_mode);
+    if (mlp_precision != CED_MLP_F16X2 && mlp_precision != CED_MLP_F16) return -1;
     const int64_t frags = time_mode ? ced::HalfBlob<true>::FRAGS : ced::HalfBlob<false>::FRAGS;
     return frags * (ced::kFragHalves / 2) * (mlp_precision == CED_MLP_F16X2 ? 2 : 1);
 }
@@ -425,52 +375,26 @@ extern "C" int ced_pack_field_weights_half(int use_div_offsets, int time_mode, i
     memset(out, 0, (size_t)words * 4);
     _Float16 *hi = reinterpret_cast<_Float16 *>(out);
     _Float16 *lo = hi + (te ? ced::HalfBlob<true>::FRAGS : ced::HalfBlob<false>::FRAGS) * ced::kFragHalves;
-    enum { ROW_NATURAL, ROW_HIDDEN, ROW_BASE_OUT };
-    enum { COL_NATURAL, COL_HASH, COL_HEAD };
+    using namespace ced;
     struct L { const float *w; int n_out, n_in, nb, ks, frag, row, col; };
     const int base_in = te ? 41 : 32, n_mo = use_div_offsets ? 6 : 3, ksb0 = te ? 2 : 1;
     int fr[9];
     if (te) {
-        using B = ced::HalfBlob<true>;
+        using B = HalfBlob<true>;
         const int o[9] = { B::M0, B::M1, B::M2, B::M3, B::B0, B::B1, B::H0, B::H1, B::H2 };
         for (int i = 0; i < 9; ++i) fr[i] = o[i];
     } else {
-        using B = ced::HalfBlob<false>;
+        using B = HalfBlob<false>;
         const int o[9] = { B::M0, B::M1, B::M2, B::M3, B::B0, B::B1, B::H0, B::H1, B::H2 };
         for (int i = 0; i < 9; ++i) fr[i] = o[i];
     }
     const L layers[9] = {
-        { m_w0, 64, 32, 4, 1, fr[0], ROW_HIDDEN, COL_NATURAL },   { m_w1, 64, 64, 4, 2, fr[1], ROW_HIDDEN, COL_NATURAL },
-        { m_w2, 64, 64, 4, 2, fr[2], ROW_HIDDEN, COL_NATURAL },   { m_w3, n_mo, 64, 1, 2, fr[3], ROW_NATURAL, COL_NATURAL },
-        { b_w0, 64, base_in, 4, ksb0, fr[4], ROW_HIDDEN, COL_HASH }, { b_w1, 16, 64, 1, 2, fr[5], ROW_BASE_OUT, COL_NATURAL },
-        { h_w0, 64, 19, 4, 1, fr[6], ROW_HIDDEN, COL_HEAD },      { h_w1, 64, 64, 4, 2, fr[7], ROW_HIDDEN, COL_NATURAL },
-        { h_w2, 3, 64, 1, 2, fr[8], ROW_NATURAL, COL_NATURAL },
+        { m_w0, 64, 32, 4, 1, fr[0], HALF_ROW_HIDDEN, HALF_COL_NATURAL },   { m_w1, 64, 64, 4, 2, fr[1], HALF_ROW_HIDDEN, HALF_COL_NATURAL },
+        { m_w2, 64, 64, 4, 2, fr[2], HALF_ROW_HIDDEN, HALF_COL_NATURAL },   { m_w3, n_mo, 64, 1, 2, fr[3], HALF_ROW_NATURAL, HALF_COL_NATURAL },
+        { b_w0, 64, base_in, 4, ksb0, fr[4], HALF_ROW_HIDDEN, HALF_COL_HASH }, { b_w1, 16, 64, 1, 2, fr[5], HALF_ROW_BASE_OUT, HALF_COL_NATURAL },
+        { h_w0, 64, 19, 4, 1, fr[6], HALF_ROW_HIDDEN, HALF_COL_HEAD },      { h_w1, 64, 64, 4, 2, fr[7], HALF_ROW_HIDDEN, HALF_COL_NATURAL },
+        { h_w2, 3, 64, 1, 2, fr[8], HALF_ROW_NATURAL, HALF_COL_NATURAL },
     };
-    for (const L &l : layers) {
-        for (int p = 0; p < l.nb * 16; ++p) {
-            int neuron = p;
-            if (l.row == ROW_HIDDEN) neuron = ced::half_hidden_neuron(p);
-            else if (l.row == ROW_BASE_OUT) neuron = ced::half_base_out_neuron(p);
-            if (neuron >= l.n_out) continue;
-            for (int k = 0; k < l.ks * 32; ++k) {
-                const int g = (k % 32) / 8, e = k % 8;
-                int in = k;                                  // which input of the layer sits at operand position k
-                if (l.col == COL_HASH) {
-                    if (k < 32) in = 2 * (4 * (e >> 1) + g) + (e & 1);          // level 4i + g, feature f at e = 2i + f
-                    else in = (e < 3 && 4 * e + g <= 8) ? 32 + 4 * e + g : -1;   // time feature 4e + g
-                } else if (l.col == COL_HEAD) {
-                    if (e == 0) in = g;                                          // SH component g
-                    else if (e <= 4 && 4 * g + e - 1 < 15) in = 4 + 4 * g + e - 1;   // geometry feature 4g + e - 1
-                    else in = -1;
-                }
-                if (in < 0 || in >= l.n_in) continue;
-                const float w = l.w[(int64_t)neuron * l.n_in + in];
-                const _Float16 h = (_Float16)w;
-                const int64_t idx = ((int64_t)(l.frag + (p / 16) * l.ks + k / 32) * 64 + 16 * g + (p % 16)) * 8 + e;
-                hi[idx] = h;
-                if (split) lo[idx] = (_Float16)(w - (float)h);
-            }
-        }
-    }
+    for (const L &l : layers) pack_half_layer(l.w, l.n_out, l.n_in, l.nb, l.ks, l.frag, l.row, l.col, hi, split ? lo : nullptr);
     return CED_OK;
 }

@@ -1,0 +1,134 @@
+// Device-side pieces of the half-precision-MFMA MLP layers (fp16 operands, fp32 accumulate) of field_half.hip:
+// operand packing, the layer loop with its operand guard, the accumulator -> operand step, and the
+// host/device row maps.
+#pragma once
+#include <cstdint>
+
+#include "ced_common.hpp"
+#include "field_device.hpp"
+
+namespace ced {
+
+typedef _Float16 h8 __attribute__((ext_vector_type(8)));
+
+constexpr int kFragHalves = 512;      // one (nb, ks) A fragment: 64 lanes x 8 halves
+
+// accumulator row -> neuron of a 64-wide hidden layer (see the header comment)
+__host__ __device__ constexpr int half_hidden_neuron(int p)
+{
+    const int nb = p >> 4, g = (p >> 2) & 3, r = p & 3;
+    return 32 * (nb >> 1) + 8 * g + 4 * (nb & 1) + r;
+}
+// mlp_base output: row p < 15 is geometry feature p (neuron 1 + p), row 15 the raw density (neuron 0)
+__host__ __device__ constexpr int half_base_out_neuron(int p) { return p < 15 ? p + 1 : 0; }
+
+constexpr float kHalfMax = 65504.0f;
+
+#ifndef CED_HALF_MFMA_GUARD
+#define CED_HALF_MFMA_GUARD 3
+#endif
+
+// eight fp32 values -> packed fp16 operand (and the fp16 remainder in F16X2 mode)
+template <bool SPLIT> __device__ __forceinline__ void to_half8(const float (&v)[8], h8 &hi, h8 &lo)
+{
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+        const _Float16 h = (_Float16)v[e];
+        hi[e] = h;
+        if constexpr (SPLIT) lo[e] = (_Float16)(v[e] - (float)h);
+    }
+}
+
+typedef _Float16 h4 __attribute__((ext_vector_type(4)));
+
+// One K = 32 product block of D^T = W * X^T.  gfx950's v_mfma_f32_16x16x32_f16 does it in one instruction,
+// but under ROCm 7.2 kernels built on it were NOT reproducible on MI355X: with two or three waves per SIMD about
+// 0.2 % of the 16-sample tiles came out wrong, different ones on every run, always the tile whose MFMA is the last
+// reader of the group's A operand.  Scheduler fences and s_nop pads around the MFMA groups and pinning the operand
+// registers moved the failure between the f16x2 and f16 variants but never removed it from both
+// (tools/debug_half.py is the reproducer; define CED_HALF_MFMA_K32 to build that form).  The same block issued as
+// two v_mfma_f32_16x16x16_f16 over the low / high four halves of each lane's operands -- the same index pairing,
+// hence the same sum, no data movement -- is reproducible over repeated 15 M-sample launches in both variants, and
+// is what ships (f16x2: 3.6 instead of 4.2 Gsamples/s; f16: 5.1 either way).
+__device__ __forceinline__ f4 mfma_k32(const h8 &a, const h8 &b, f4 c)
+{
+#ifdef CED_HALF_MFMA_K32
+    return __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, c, 0, 0, 0);
+#else
+    const h4 a0 = { a[0], a[1], a[2], a[3] }, a1 = { a[4], a[5], a[6], a[7] };
+    const h4 b0 = { b[0], b[1], b[2], b[3] }, b1 = { b[4], b[5], b[6], b[7] };
+    c = __builtin_amdgcn_mfma_f32_16x16x16f16(a0, b0, c, 0, 0, 0);
+    return __builtin_amdgcn_mfma_f32_16x16x16f16(a1, b1, c, 0, 0, 0);
+#endif
+}
+
+template <int KS, int NB, int NT, bool SPLIT>
+__device__ __forceinline__ void mlp_layer_h(const _Float16 *__restrict__ whi, const _Float16 *__restrict__ wlo, int lane,
+                                            const h8 (&Bh)[NT][2], const h8 (&Bl)[NT][2], f4 (&D)[NT][4])
+{
+#pragma unroll
+    for (int nb = 0; nb < NB; ++nb) {
+        f4 acc[NT];
+#pragma unroll
+        for (int j = 0; j < NT; ++j) acc[j] = f4{ 0.0f, 0.0f, 0.0f, 0.0f };
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) {
+            const h8 ah = *reinterpret_cast<const h8 *>(whi + ((nb * KS + ks) * 64 + lane) * 8);
+            h8 al = ah;
+            if constexpr (SPLIT) {
+                al = *reinterpret_cast<const h8 *>(wlo + ((nb * KS + ks) * 64 + lane) * 8);
+#pragma unroll
+                for (int j = 0; j < NT; ++j) acc[j] = mfma_k32(al, Bh[j][ks], acc[j]);
+#pragma unroll
+                for (int j = 0; j < NT; ++j) acc[j] = mfma_k32(ah, Bl[j][ks], acc[j]);
+            }
+#pragma unroll
+            for (int j = 0; j < NT; ++j) acc[j] = mfma_k32(ah, Bh[j][ks], acc[j]);
+            // Group fence: the MFMAs of a group issue back to back and the group's operands stay allocated
+            // until the pad below has passed (a left-over of the hunt described at mfma_k32; it costs nothing
+            // measurable and keeps the conversions of the next operands out of the MFMA stream).
+            __builtin_amdgcn_sched_barrier(0);
+            asm volatile("s_nop %0" ::"n"(CED_HALF_MFMA_GUARD));
+            asm volatile("" ::"v"(ah));
+            if constexpr (SPLIT) asm volatile("" ::"v"(al));
+            __builtin_amdgcn_sched_barrier(0);
+        }
+#pragma unroll
+        for (int j = 0; j < NT; ++j) D[j][nb] = acc[j];
+    }
+    // the same for the B operands, whose last readers are the MFMAs of the last group
+#pragma unroll
+    for (int j = 0; j < NT; ++j) {
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) {
+            asm volatile("" ::"v"(Bh[j][ks]));
+            if constexpr (SPLIT) asm volatile("" ::"v"(Bl[j][ks]));
+        }
+    }
+    __builtin_amdgcn_sched_barrier(0);
+}
+
+// ReLU + saturation to the fp16 range (one v_med3_f32), then the accumulator registers become the
+// next layer's operand: k-step ks takes D[2ks][0..3], D[2ks+1][0..3].
+template <int NT, bool SPLIT>
+__device__ __forceinline__ void to_operand_h(const f4 (&D)[NT][4], h8 (&Bh)[NT][2], h8 (&Bl)[NT][2])
+{
+#pragma unroll
+    for (int j = 0; j < NT; ++j) {
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            float v[8];
+#pragma unroll
+            for (int e = 0; e < 8; ++e) v[e] = __builtin_amdgcn_fmed3f(D[j][2 * ks + (e >> 2)][e & 3], 0.0f, kHalfMax);
+            to_half8<SPLIT>(v, Bh[j][ks], Bl[j][ks]);
+        }
+    }
+}
+
+// host: one layer W[n_out][n_in] into 16x16x32 A-fragment order at fragment `frag` (see field_half.hip)
+enum HalfRowMap { HALF_ROW_NATURAL, HALF_ROW_HIDDEN, HALF_ROW_BASE_OUT };
+enum HalfColMap { HALF_COL_NATURAL, HALF_COL_HASH, HALF_COL_HEAD };
+void pack_half_layer(const float *w, int n_out, int n_in, int nb, int ks, int frag, int row_map, int col_map,
+                     _Float16 *hi, _Float16 *lo);
+
+}  // namespace ced

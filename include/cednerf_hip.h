@@ -63,7 +63,7 @@ typedef struct ced_field_desc {
     float moving_step;           /* model.py:151, train_real.py:104,136,169 */
     int32_t use_div_offsets;     /* model.py:356-358 */
     int32_t time_mode;           /* 0 none, 1 SinusoidalEncoder, 2 SinusoidalEncoderWithExp (model.py:386-396) */
-    int32_t mlp_precision;       /* CED_MLP_F32 / CED_MLP_F16X2 / CED_MLP_F16: arithmetic of the three MLPs (below) */
+    int32_t mlp_precision;       /* CED_MLP_*: arithmetic of the three MLPs (below) */
     const void *packed_weights;  /* device: blob written by ced_pack_field_weights[_half] for that precision */
     uint64_t packed_floats;      /* its size in 32-bit words: ced_packed_weight_words() */
     ced_hash_desc hash;
@@ -80,8 +80,8 @@ int ced_set_option(const char *key, int value);
 
 /* Arithmetic of xyz_wrap / mlp_base / mlp_head (everything else is fp32 in every mode):
  *   CED_MLP_F32    v_mfma_f32_16x16x4_f32, an ascending-k fp32 FMA chain: bit-identical to the CPU oracle.
- *   CED_MLP_F16X2  every operand split into two fp16 numbers (22 significant bits), three
- *                  v_mfma_f32_16x16x32_f16 per product block, fp32 accumulation: fp32-grade results.
+ *   CED_MLP_F16X2  every operand split into two fp16 numbers (22 significant bits), three fp16 MFMA
+ *                  blocks per product block, fp32 accumulation: fp32-grade results.
  *   CED_MLP_F16    operands rounded to fp16, fp32 accumulation: the precision class of the reference's
  *                  tiny-cuda-nn FullyFusedMLP (cednerf/model.py:200-222,280-309).
  * The half modes assume |weights|, |activations| <= 65504 (activations saturate there), like tcnn. */

@@ -30,9 +30,13 @@ def run(prec, n_use, rays):
 for n_use in (5037, 200000, 2000000, N):
     for rays in (False, True):
         ref = run("f32", n_use, rays)
-        for prec in ("f16x2",):
+        for prec in os.environ.get("PRECS", "f16x2").split(","):
             a = run(prec, n_use, rays); b = run(prec, n_use, rays)
             err = (a[0] - ref[0]).abs().max(dim=1).values
+            nd = ((a[0] != b[0]).any(dim=1) | (a[1] != b[1])).nonzero().flatten()
+            print(f"   run-to-run differing samples {nd.numel()} first {nd[:10].tolist()} %32 hist {torch.bincount(nd % 32, minlength=32).tolist() if nd.numel() else ''}")
+            sbad = (a[1] != ref[1]).nonzero().flatten()
+            print(f"   sigma mismatches {sbad.numel()} first {sbad[:8].tolist()} %32 hist {torch.bincount(sbad % 32, minlength=32).tolist() if sbad.numel() else ''}")
             bad = (err > 2e-3).nonzero().flatten()
             print(f"n={n_use} rays={rays} {prec}: max err {err.max().item():.3e}, bad {bad.numel()}, deterministic {torch.equal(a[0], b[0])}",
                   "first bad", bad[:12].tolist(), "bad%32 hist", torch.bincount(bad % 32, minlength=32).tolist() if bad.numel() else "")
