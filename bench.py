@@ -43,7 +43,7 @@ def parse():
                     help="arithmetic of the three MLPs (include/cednerf_hip.h CED_MLP_*): f32 = exact fp32 MFMA chain, "
                          "bit-identical to the CPU oracle; f16x2 = split-fp16 MFMA with fp32 accumulation, fp32-grade "
                          "(<= 1e-4 on pixels, same sample counts); f16 = fp16 operands, the reference's tcnn class")
-    ap.add_argument("--pmc-json", default=os.path.join(ROOT, "profiles", "r01_pmc_field.json"),
+    ap.add_argument("--pmc-json", default=None,
                     help="per-launch HBM traffic of the field kernel from the rocprofv3 --pmc passes (tools/pmc_summary.py)")
     ap.add_argument("--regime", default="trained")
     ap.add_argument("--max-samples", type=int, default=1024)
@@ -286,9 +286,10 @@ def main():
         gbs = samples_per_launch * (ALG_BYTES_PER_SAMPLE_F16 if fp16 else ALG_BYTES_PER_SAMPLE_F32) / (avg_ms * 1e-3) / 1e9
         traffic = None
         exact_kernel = args.mlp_precision == "f32"
-        if args.scene == "dnerf" and not fp16 and os.path.exists(args.pmc_json):
+        pmc_json = args.pmc_json or os.path.join(ROOT, "profiles", f"r01_final_{args.mlp_precision}_pmc.json")
+        if args.scene == "dnerf" and not fp16 and os.path.exists(pmc_json):
             try:        # HBM bytes per launch from the committed PMC passes of this same workload
-                pj = json.load(open(args.pmc_json))
+                pj = json.load(open(pmc_json))
                 kpat = "void ced::field_kernel" if exact_kernel else "void ced::field_half_kernel"
                 k = [v for n, v in pj.items() if n.startswith(kpat)][0]
                 traffic = k["fetch_bytes_per_launch"] + k["write_bytes_per_launch"]

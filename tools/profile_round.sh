@@ -1,0 +1,28 @@
+#!/bin/bash
+# Produces the per-round profile artefacts on the GPU box under gpurun_out/prof/ (copy what is to be judged into
+# profiles/).  Counters are collected in their own passes (never together with trace domains).
+# usage (on the GPU box): bash tools/profile_round.sh [tag]
+set -e
+TAG=${1:-r01_final}
+R=$GRAFT_REPO_ROOT
+OUT=$R/gpurun_out/prof
+mkdir -p $OUT
+cd /tmp && export TMPDIR=/tmp
+for prec in f32 f16x2; do
+  ARGS="$R/bench.py --steps 5 --warmup 1 --no-cpu-baseline --also= --mlp-precision $prec"
+  # 1. the bench line itself (not under the profiler)
+  timeout -k 10 300 python3 $ARGS > $OUT/${TAG}_${prec}_bench.json 2> $OUT/${TAG}_${prec}_bench.err
+  echo "bench $prec done"
+  # 2. per-kernel times
+  timeout -k 10 400 rocprofv3 --kernel-trace --stats -d $OUT/kt_$prec -o kt --output-format csv -- python3 $ARGS > $OUT/${TAG}_${prec}_bench_under_rocprof.json 2> $OUT/kt_$prec.err
+  cp $(ls $OUT/kt_$prec/*kernel_stats.csv | head -1) $OUT/${TAG}_${prec}_kernel_stats.csv
+  echo "kernel trace $prec done"
+  # 3. HBM bytes: FETCH_SIZE and WRITE_SIZE in separate passes
+  timeout -k 10 400 rocprofv3 --pmc FETCH_SIZE -d $OUT/pmc_fetch_$prec -o f --output-format csv -- python3 $ARGS > /dev/null 2> $OUT/pmc_fetch_$prec.err
+  timeout -k 10 400 rocprofv3 --pmc WRITE_SIZE -d $OUT/pmc_write_$prec -o w --output-format csv -- python3 $ARGS > /dev/null 2> $OUT/pmc_write_$prec.err
+  python3 $R/tools/pmc_summary.py $OUT/${TAG}_${prec}_pmc.json $OUT/pmc_fetch_$prec $OUT/pmc_write_$prec > /dev/null
+  echo "pmc $prec done"
+done
+# the default bench.py line (exact mode + the fast modes + cpu baselines)
+timeout -k 10 400 python3 $R/bench.py > $OUT/${TAG}_bench_default.json 2> $OUT/${TAG}_bench_default.err
+echo "default bench done"
