@@ -121,6 +121,8 @@ def main():
     from ced_nerf_amd.nerfacc_api import OccGridEstimator
     from ced_nerf_amd.utils import Rays
     _lib.lib()
+    if os.environ.get("CED_FIELD_SPREAD_TILES") is not None:
+        _lib.check(_lib.lib().ced_set_option(b"field_spread_tiles", int(os.environ["CED_FIELD_SPREAD_TILES"])))
 
     T = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)
     # A step renders `lanes` x `world` frames of a turntable video (consecutive azimuths): every lane is

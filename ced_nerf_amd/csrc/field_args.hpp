@@ -22,6 +22,7 @@ struct FieldArgs {
     const void *weights;                              // packed blob of the descriptor's mlp_precision
     int table_dtype, temporal;
     int stagger;                                      // start-up phase offset between SIMD-mates (s_sleep(127) units)
+    int spread_tiles;                                 // tile -> wave mapping (field.hip); ced_set_option("field_spread_tiles")
     int level_mode;                                   // 2 bits per gather slot: 0 mixed, 1 all dense, 2 all hashed
     const void *table;
     float scale[CED_MAX_LEVELS];
@@ -29,6 +30,7 @@ struct FieldArgs {
 };
 
 extern bool g_march_early_out;
+extern int g_field_spread_tiles;
 
 // Fills the field/hash parts of A from the descriptor, validates, and launches on `stream`.
 int launch_field(const ced_field_desc *d, FieldArgs &A, void *stream);

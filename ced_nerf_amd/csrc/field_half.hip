@@ -81,7 +81,10 @@ __global__ __launch_bounds__(THREADS) void field_half_kernel(FieldArgs A)
     const int64_t n_tiles = (n_eff + TILE - 1) / TILE;
     const float extent[3] = { A.aabb[3] - A.aabb[0], A.aabb[4] - A.aabb[1], A.aabb[5] - A.aabb[2] };
 
-    for (int64_t tile = (int64_t)blockIdx.x * WAVES + wave; tile < n_tiles; tile += (int64_t)gridDim.x * WAVES) {
+    // tiles are dealt in groups of four (one per SIMD) across all workgroups first: see field.hip
+    const int64_t first_tile = A.spread_tiles ? ((int64_t)(wave >> 2) * gridDim.x + blockIdx.x) * 4 + (wave & 3)
+                                              : (int64_t)blockIdx.x * WAVES + wave;
+    for (int64_t tile = first_tile; tile < n_tiles; tile += (int64_t)gridDim.x * WAVES) {
         // opaque LDS base per tile: keeps the A-fragment reads inside the loop (see field.hip)
         int lds_off = 0;
         asm volatile("" : "+v"(lds_off));
@@ -314,7 +317,7 @@ int launch_field_half(FieldArgs &A, int time_mode, int precision, void *stream)
     auto launch = [&](auto kernel, int nt, int threads) {
         const int64_t n_tiles = (A.n + 16 * nt - 1) / (16 * nt);
         const int waves = threads / 64;
-        int64_t blocks = (n_tiles + waves - 1) / waves;
+        int64_t blocks = A.spread_tiles ? (n_tiles + 3) / 4 : (n_tiles + waves - 1) / waves;
         if (blocks > 256) blocks = 256;     // one resident workgroup per CU, persistent over tiles
         hipLaunchKernelGGL(kernel, dim3((unsigned)blocks), dim3(threads), 0, (hipStream_t)stream, A);
     };

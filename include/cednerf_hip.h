@@ -74,8 +74,12 @@ const char *ced_last_error_string(void);
 
 /* Tuning knobs (process-wide).  "field_variant": launch geometry of the fused field kernel,
  * 0 = 4 column tiles x 512 threads, 1 = 2 x 512, 2 = 2 x 768 (default), 3 = 2 x 1024;
+ * "half_variant": the same for the half-precision kernels, 0 = 2 x 768 (default), 1 = 2 x 512, 2 = 2 x 1024;
+ * "field_spread_tiles": 1 (default) deals the sample tiles of a launch across all CUs in groups of four before
+ * any CU takes more (shorter last round, lower frame latency), 0 = contiguous tiles per workgroup;
+ * "field_stagger": start-up phase offset between the waves of a SIMD (0 = none, default);
  * "march_early_out": 1 (default) lets ced_render_image_test stop walking a ray once a dilated
- * brick mask proves nothing occupied lies ahead, 0 walks every cell.  Results are identical. */
+ * brick mask proves nothing occupied lies ahead, 0 walks every cell.  Results are identical for every setting. */
 int ced_set_option(const char *key, int value);
 
 /* Arithmetic of xyz_wrap / mlp_base / mlp_head (everything else is fp32 in every mode):
