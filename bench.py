@@ -158,7 +158,8 @@ def main():
         tracers.append([ops.FrameTracer(capacity=96, with_events=True) for _ in range(min(args.steps, 24))])
         r.tracer = tracers[-1][0]
         lane_renderers.append(r)
-    renderer = cdist.PipelinedRenderer(lane_renderers)
+    # multi-rank: the pixel all-gather of one step overlaps the next step's kernels (own stream, no read-back)
+    renderer = cdist.PipelinedRenderer(lane_renderers, async_gather=world > 1)
     field_ms, field_launches, field_samples = [0.0], [0], [0]
     step_no = [0]
 

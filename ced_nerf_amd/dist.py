@@ -89,8 +89,10 @@ class ShardedRenderer:
         return rgb, op, dp, int(n_samples)
 
     @torch.no_grad()
-    def gather(self, local) -> Dict:
-        """All-gather the shards' pixels and put them back in raster order (one collective)."""
+    def gather(self, local, sync_total: bool = True) -> Dict:
+        """All-gather the shards' pixels and put them back in raster order (one collective).  sync_total=False
+        leaves the all-rank sample count on the device (`total_samples_tensor`, float64 scalar) instead of
+        reading it back, so the call only enqueues work (used when gathers overlap the next frames)."""
         F, H, W = self.shape
         rgb, op, dp, n_samples = local
         if self.gather_index is None:
@@ -106,13 +108,15 @@ class ShardedRenderer:
         gathered = torch.empty((self.world, self.n_pad + 1, 5), device=rgb.device, dtype=torch.float32)
         dist.all_gather_into_tensor(gathered.view(-1, 5), payload)
         tail = gathered[:, -1, :2].to(torch.float64)
-        total = int((tail[:, 0] * 65536.0 + tail[:, 1]).sum().item())
+        total_t = (tail[:, 0] * 65536.0 + tail[:, 1]).sum()
+        total = int(total_t.item()) if sync_total else None
         n_rays = F * H * W
         image = torch.empty((n_rays + 1, 5), device=rgb.device, dtype=torch.float32)
         image[self.gather_index] = gathered[:, :-1, :].reshape(-1, 5)
         image = image[:n_rays]
         return dict(rgb=image[:, 0:3].reshape(F, H, W, 3), opacity=image[:, 3:4].reshape(F, H, W, 1),
-                    depth=image[:, 4:5].reshape(F, H, W, 1), local_samples=n_samples, total_samples=total)
+                    depth=image[:, 4:5].reshape(F, H, W, 1), local_samples=n_samples, total_samples=total,
+                    total_samples_tensor=total_t)
 
     @torch.no_grad()
     def render(self, timestamps: torch.Tensor) -> Dict:
@@ -127,11 +131,18 @@ class PipelinedRenderer:
     MFMA-bound field kernel of another (frames are independent: train_real.py:531-558 renders them
     one after the other).  Every lane is a complete render_image_test call, so per-frame results
     are exactly those of rendering the frames one at a time.  Collectives are issued afterwards by
-    the calling thread, lane by lane, i.e. in the same order on every rank."""
+    the calling thread, lane by lane, i.e. in the same order on every rank.
 
-    def __init__(self, lanes, share_field_stream: bool = False):
+    async_gather=True (multi-rank video rendering): the gathers and the un-permute run on a communication
+    stream of their own and `render` returns without waiting for them, so the exchange of one step overlaps
+    the marching / field kernels of the next; the returned images are valid after `wait_gathers()` (or a
+    device synchronise), and the all-rank sample count stays on the device (`total_samples_tensor`)."""
+
+    def __init__(self, lanes, share_field_stream: bool = False, async_gather: bool = False):
         from concurrent.futures import ThreadPoolExecutor
         self.lanes = list(lanes)
+        self.async_gather = bool(async_gather)
+        self.comm_stream = None
         self.streams = [torch.cuda.Stream(device=l.device) if torch.cuda.is_available() and str(l.device) != "cpu"
                         else None for l in self.lanes]
         self.pool = ThreadPoolExecutor(max_workers=len(self.lanes)) if len(self.lanes) > 1 else None
@@ -161,7 +172,23 @@ class PipelinedRenderer:
                     s.wait_stream(main)             # the inputs were produced on the caller's stream
             futures = [self.pool.submit(self._lane, i, timestamps) for i in range(len(self.lanes))]
             locals_ = [f.result() for f in futures]
-            if main is not None:
+            if main is not None and not self.async_gather:
                 for s in self.streams:
                     main.wait_stream(s)
-        return [lane.gather(loc) for lane, loc in zip(self.lanes, locals_)]
+        if not self.async_gather or self.streams[0] is None:
+            return [lane.gather(loc) for lane, loc in zip(self.lanes, locals_)]
+        if self.comm_stream is None:
+            self.comm_stream = torch.cuda.Stream(device=self.lanes[0].device)
+        outs = []
+        with torch.cuda.stream(self.comm_stream):
+            for lane, loc, s in zip(self.lanes, locals_, self.streams):
+                self.comm_stream.wait_stream(s)
+                for t in loc[:3]:
+                    t.record_stream(self.comm_stream)       # produced on the lane's stream, consumed here
+                outs.append(lane.gather(loc, sync_total=False))
+        return outs
+
+    def wait_gathers(self) -> None:
+        """Make the caller's stream wait for every gather issued so far (async_gather mode)."""
+        if self.comm_stream is not None:
+            torch.cuda.current_stream().wait_stream(self.comm_stream)

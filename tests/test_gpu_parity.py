@@ -584,6 +584,24 @@ def test_sharded_renderer_collective_path_on_gpu(oracle, full_frame):
         assert out["total_samples"] == out["local_samples"] == want[3] and want[3] > 1000
         assert (out["rgb"][0] - want[0]).abs().max().item() <= 1e-4
         assert (out["depth"][0] - want[2]).abs().max().item() <= 1e-4
+        # frames in flight with the gathers on their own stream and no read-back (what bench.py does with N > 1
+        # ranks): two steps back to back, then wait -- every step's image equals the synchronous one
+        from ced_nerf_amd.dist import PipelinedRenderer
+        lanes = []
+        for k in range(2):
+            lr = ShardedRenderer(f, est, 1, 0, torch.device(DEV), max_samples=1024, render_kwargs=rk, force_collective=True)
+            lr.set_rays(o, d)
+            lanes.append(lr)
+        pipe = PipelinedRenderer(lanes, async_gather=True)
+        steps = [pipe.render(ts) for _ in range(3)]
+        pipe.wait_gathers()
+        torch.cuda.synchronize()
+        for outs in steps:
+            for a in outs:
+                assert a["total_samples"] is None and int(a["total_samples_tensor"].item()) == want[3]
+                assert a["local_samples"] == want[3]
+                assert torch.equal(a["rgb"], out["rgb"]) and torch.equal(a["depth"], out["depth"])
+                assert torch.equal(a["opacity"], out["opacity"])
     finally:
         if created:
             dist.destroy_process_group()
