@@ -533,6 +533,41 @@ def test_full_size_frame_properties(oracle, full_frame):
     assert torch.equal(full[0].reshape(-1, 3)[torch.from_numpy(pick).to(DEV)], g[0])
 
 
+@pytest.mark.parametrize("name,wh,min_samples", [("hypernerf", (536, 960), 4), ("dynerf", (1352, 1014), 4)])
+def test_full_size_other_configs(oracle, name, wh, min_samples):
+    """BASELINE configs 3 and 4 at their full sizes (HyperNeRF 536x960 with -te -ta -df, 2 grid levels, cone 0.004;
+    DyNeRF 1352x1014, 4 levels): size-independent properties of render_image_test and an oracle check of a ray
+    subset through the per-ray-deterministic render_image."""
+    from ced_nerf_amd import ops
+    from ced_nerf_amd.utils import Rays, render_image, render_image_test, render_image_test_staged
+    sc = _scene(name, wh[0], wh[1], "trained")
+    of, oest, f, est, rays, rk = _setup(oracle, sc)
+    ts = T(sc["timestamps"])
+    n_rays = wh[0] * wh[1]
+    tracer = ops.FrameTracer(capacity=1100, with_events=False)
+    rgb, op, dp, total = render_image_test(1024, f, est, rays, timestamps=ts, tracer=tracer, **rk)
+    its = tracer.iterations()
+    assert sum(i["n_new"] for i in its) == total and its[0]["n_alive"] == n_rays
+    assert all(i["n_samples"] == max(min(n_rays // i["n_alive"], 64), min_samples) for i in its)      # utils.py:235
+    assert all(i["n_new"] <= i["n_alive"] * i["n_samples"] for i in its)
+    rgb2, op2, dp2, total2 = render_image_test(1024, f, est, rays, timestamps=ts, **rk)
+    assert total2 == total and torch.equal(rgb, rgb2) and torch.equal(dp, dp2) and torch.equal(op, op2)
+    s_rgb, s_op, s_dp, s_total = render_image_test_staged(1024, f, est, rays, timestamps=ts, **rk)
+    assert s_total == total and torch.equal(s_rgb, rgb) and torch.equal(s_op, op) and torch.equal(s_dp, dp)
+    opn = N(op)
+    assert opn.min() >= 0.0 and opn.max() <= 1.0 + 1e-5 and (opn > 0.5).mean() > 0.01
+    # oracle on a subset of rays
+    rng = np.random.default_rng(1)
+    hit_idx = np.flatnonzero(opn.reshape(-1) > 0)
+    pick = np.concatenate([rng.choice(hit_idx, 600, replace=False), rng.choice(n_rays, 300, replace=False)])
+    so = sc["origins"].reshape(-1, 3)[pick]; sd = sc["viewdirs"].reshape(-1, 3)[pick]
+    w = oracle.render_image(of, oest, so, sd, timestamps=sc["timestamps"], **sc["render"])
+    g = render_image(f, est, Rays(T(so), T(sd)), timestamps=ts, **rk)
+    assert g[3] == w[3] and w[3] > 100
+    for i, nm in enumerate(("colors", "opacities", "depths")):
+        assert_bitexact(N(g[i]), w[i], f"{name} full-size subset {nm}")
+
+
 def test_full_size_frames_f16x2_match_exact_mode(oracle, full_frame):
     """The frames bench.py times (800x800 turntable, azimuth 30/42/54 deg), rendered with the split-fp16 MLPs,
     against the exact fp32 mode (itself bit-identical to the oracle: tests above): pixels within the north-star
