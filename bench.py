@@ -151,7 +151,8 @@ def main():
     lane_renderers, tracers = [], []
     for l in range(lanes):
         fr = frames[l * world:(l + 1) * world]
-        r = cdist.ShardedRenderer(field, est, world, rank, dev, max_samples=args.max_samples, render_kwargs=rk)
+        r = cdist.ShardedRenderer(field, est, world, rank, dev, max_samples=args.max_samples, render_kwargs=rk,
+                                  tile_order=os.environ.get("CED_TILE_ORDER", "1") != "0")
         r.set_rays(torch.stack([T(f["origins"]) for f in fr]), torch.stack([T(f["viewdirs"]) for f in fr]))
         # HIP events around every field launch; one event set per timed step so nothing is read back
         # (hipEventElapsedTime) inside the timed region

@@ -40,7 +40,7 @@ class ShardedRenderer:
 
     def __init__(self, field, estimator, world: int, rank: int, device, max_samples: int = 1024,
                  render_kwargs: Optional[Dict] = None, render_fn: Optional[Callable] = None,
-                 force_collective: bool = False):
+                 force_collective: bool = False, tile_order: bool = False):
         self.field, self.estimator = field, estimator
         self.world, self.rank, self.device = world, rank, device
         self.max_samples = max_samples
@@ -50,6 +50,10 @@ class ShardedRenderer:
         self.tracer = None             # optional ops.FrameTracer handed to the native frame call
         self.field_stream = None       # optional stream shared with other in-flight frames (PipelinedRenderer)
         self.force_collective = force_collective   # run the shard/gather/un-permute path even when world == 1
+        # world == 1 without a collective: still walk the rays in 8x8-tile order (a wave's 64 rays are then one
+        # tile, not a 64-pixel strip: more coherent marching depths and hash cells) and un-permute the pixels
+        self.tile_order = tile_order
+        self.unpermute = None
 
     def _hip_render(self, rays_o, rays_d, timestamps):
         from .utils import Rays, render_image_test
@@ -63,9 +67,18 @@ class ShardedRenderer:
         self.shape = (F, H, W)
         o = origins.reshape(-1, 3); d = viewdirs.reshape(-1, 3)
         if self.world == 1 and not self.force_collective:
-            self.local_o, self.local_d = o.contiguous(), d.contiguous()
             self.n_local = self.n_pad = o.shape[0]
             self.gather_index = None
+            if self.tile_order:
+                _, shards = tile_cyclic_assignment(F, H, W, 1)
+                order = torch.from_numpy(shards[0].astype(np.int64)).to(o.device)        # tile-major -> flat ray id
+                self.local_o, self.local_d = o[order].contiguous(), d[order].contiguous()
+                inv = torch.empty_like(order)
+                inv[order] = torch.arange(order.numel(), device=o.device)
+                self.unpermute = inv
+            else:
+                self.local_o, self.local_d = o.contiguous(), d.contiguous()
+                self.unpermute = None
             return
         _, shards = tile_cyclic_assignment(F, H, W, self.world)
         self.n_pad = max(len(s) for s in shards)
@@ -96,6 +109,8 @@ class ShardedRenderer:
         F, H, W = self.shape
         rgb, op, dp, n_samples = local
         if self.gather_index is None:
+            if self.unpermute is not None:
+                rgb, op, dp = rgb[self.unpermute], op[self.unpermute], dp[self.unpermute]
             return dict(rgb=rgb.view(F, H, W, 3), opacity=op.view(F, H, W, 1), depth=dp.view(F, H, W, 1),
                         local_samples=n_samples, total_samples=n_samples)
         payload = torch.empty((self.n_pad + 1, 5), device=rgb.device, dtype=torch.float32)

@@ -660,6 +660,15 @@ def test_pipelined_frames_equal_sequential_frames(oracle, full_frame):
         r.set_rays(T(o)[None], T(d)[None])
         lanes.append(r)
         singles.append(render_image_test(1024, f, est, Rays(T(o), T(d)), timestamps=ts, **rk))
+    # the same frames with the rays walked in 8x8-tile order and the pixels un-permuted (bench.py's layout at one
+    # GPU): the image-global schedule does not depend on the ray order, so the bits are the same
+    for k, r in enumerate(lanes):
+        rt = ShardedRenderer(f, est, 1, 0, torch.device(DEV), max_samples=1024, render_kwargs=rk, tile_order=True)
+        rt.set_rays(r.local_o.view(1, H, W, 3), r.local_d.view(1, H, W, 3))
+        out = rt.render(ts)
+        assert out["total_samples"] == singles[k][3]
+        assert torch.equal(out["rgb"][0], singles[k][0]) and torch.equal(out["depth"][0], singles[k][2])
+        assert torch.equal(out["opacity"][0], singles[k][1])
     pipe = PipelinedRenderer(lanes)
     for _ in range(3):                                   # repeat: concurrency bugs are intermittent
         outs = pipe.render(ts)
