@@ -15,6 +15,7 @@
 #include <atomic>
 #include <cfloat>
 #include <chrono>
+#include <cstdlib>
 
 #include "ced_common.hpp"
 #include "field_args.hpp"
@@ -154,6 +155,10 @@ __global__ __launch_bounds__(256) void march_alloc_kernel(MarchArgs A)
     const bool active = slot < A.n_alive;
     const int64_t r = active ? (A.alive ? (int64_t)A.alive[slot] : slot) : 0;
     int n = 0;
+#ifdef CED_MARCH_PROFILE
+    unsigned long long mp_acc[8] = { 0, 0, 0, 0, 0, 0, 0, 0 };
+    unsigned long long mp_t = __builtin_readcyclecounter();
+#endif
     if (active) {
         const float o[3] = { A.rays_o[3 * r], A.rays_o[3 * r + 1], A.rays_o[3 * r + 2] };
         const float d[3] = { A.rays_d[3 * r], A.rays_d[3 * r + 1], A.rays_d[3 * r + 2] };
@@ -161,7 +166,11 @@ __global__ __launch_bounds__(256) void march_alloc_kernel(MarchArgs A)
         float t_term;
         n = traverse_ray(
             A.grid, o, d, A.near_planes[r], A.far_plane, A.t_sorted + r * 2 * m, A.t_indices + r * 2 * m,
-            A.hits + r * m, [&](int i, float t0, float t1) { stage[i * 64 + lane] = make_float2(t0, t1); }, t_term);
+            A.hits + r * m, [&](int i, float t0, float t1) { stage[i * 64 + lane] = make_float2(t0, t1); }, t_term
+#ifdef CED_MARCH_PROFILE
+            , mp_acc, mp_t
+#endif
+        );
         A.near_planes[r] = t_term;
     }
     // wave-inclusive prefix sum of the counts
@@ -190,7 +199,23 @@ __global__ __launch_bounds__(256) void march_alloc_kernel(MarchArgs A)
         A.t_ends[start + i] = v.y;
         A.ray_idx[start + i] = (int32_t)r;
     }
+#ifdef CED_MARCH_PROFILE
+    CED_MP(7)                       // [7] prefix sum, range reservation, copy-out
+    CED_MP_FLUSH
+#endif
 }
+
+#ifdef CED_MARCH_PROFILE
+extern "C" int ced_debug_march_profile(unsigned long long *out16, int reset)
+{
+    if (out16 && hipMemcpyFromSymbol(out16, HIP_SYMBOL(g_march_prof), 16 * sizeof(unsigned long long)) != hipSuccess) return -1;
+    if (reset) {
+        unsigned long long z[16] = { 0 };
+        if (hipMemcpyToSymbol(HIP_SYMBOL(g_march_prof), z, sizeof z) != hipSuccess) return -1;
+    }
+    return 0;
+}
+#endif
 
 // composite_prefix (cednerf/utils.py:274-299) + ray bookkeeping (utils.py:301-307) over the list of
 // alive rays; survivors (opacity <= threshold and a full sample budget) are appended to the next
@@ -433,12 +458,13 @@ extern "C" int ced_render_image_test(const ced_field_desc *field, int64_t n_rays
 
         MarchArgs M{ n_rays, rays_o, rays_d,
                      GridSpec{ binaries, aabbs, n_grids, res, step_size, cone_angle, n_samples,
-                               g_march_early_out ? W.brick_dil : nullptr, nb },
+                               g_march_early_out ? W.brick_dil : nullptr, nb, it > 0 ? 1 : 0 },
                      W.near, far_plane, cur_list, n_alive, W.t_sorted, W.t_indices, W.hits, W.t0, W.t1, W.ridx, W.packed,
                      counter };
-        // only alive rays get a lane; 256 rays per workgroup keep the resident-wave granularity fine
-        // (a workgroup lives as long as its slowest ray) while one range reservation serves 256 rays
-        const int threads = 256;
+        // only alive rays get a lane; 128 rays per workgroup (CED_MARCH_THREADS): a workgroup lives as long as its
+        // slowest ray (its waves meet at the range reservation), while one reservation still serves 128 rays
+        static const int threads_env = [] { const char *e = getenv("CED_MARCH_THREADS"); return e ? atoi(e) : 128; }();
+        const int threads = threads_env;
         hipLaunchKernelGGL(march_alloc_kernel, dim3((unsigned)((n_alive + threads - 1) / threads)), dim3(threads),
                            (size_t)threads * n_samples * sizeof(float2), stream, M);
         rc = check_launch("render_image_test (march)");

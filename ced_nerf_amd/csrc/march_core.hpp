@@ -96,6 +96,10 @@ struct GridSpec {
     // 3x3x3 bricks around b is occupied.  NULL disables it.
     const uint8_t *dilated_bricks;
     int nb;
+    // 0: also ask at the start of a segment whether all of it is clear (first iteration of a frame: most
+    // rays miss everything); 1: only after a stretch of empty cells (later iterations: a live ray stands in
+    // or next to occupied cells, the question at the start would almost always be answered "no")
+    int skip_initial_probe;
 };
 
 constexpr int kBrick = 8;      // cells per brick side
@@ -106,6 +110,24 @@ constexpr int kBrick = 8;      // cells per brick side
 constexpr int kLook = CED_KLOOK;   // DDA look-ahead (cells whose occupancy bytes are fetched together)
 
 #if defined(__HIPCC__)
+// -DCED_MARCH_PROFILE: per-wave cycle counts of the sections of traverse_ray, summed into g_march_prof
+// (diagnostic builds only; tools/debug_march_profile.py reads them)
+#ifdef CED_MARCH_PROFILE
+static __device__ unsigned long long g_march_prof[16];
+#define CED_MP_DECL unsigned long long mp_t = __builtin_readcyclecounter(); unsigned long long mp_acc[8] = {0,0,0,0,0,0,0,0};
+#define CED_MP(sec) { const unsigned long long mp_n = __builtin_readcyclecounter(); mp_acc[sec] += mp_n - mp_t; mp_t = mp_n; }
+// the lane that was busy longest speaks for the wave (its marks cover the wave's whole run)
+#define CED_MP_FLUSH { unsigned long long mp_tot = 0; for (int q = 0; q < 8; ++q) mp_tot += mp_acc[q]; \
+        unsigned long long mp_max = mp_tot; \
+        for (int off = 32; off > 0; off >>= 1) { const unsigned long long o_ = __shfl_xor(mp_max, off, 64); mp_max = o_ > mp_max ? o_ : mp_max; } \
+        const unsigned long long mp_bal = __ballot(mp_tot == mp_max); \
+        if ((threadIdx.x & 63) == (unsigned)__builtin_ctzll(mp_bal)) { for (int q = 0; q < 8; ++q) atomicAdd(&g_march_prof[q], mp_acc[q]); atomicAdd(&g_march_prof[8], 1ull); } }
+#else
+#define CED_MP_DECL
+#define CED_MP(sec)
+#define CED_MP_FLUSH
+#endif
+
 // Conservative emptiness test of the ray segment [t_a, t_b] on grid level `lvl`: true only if no cell
 // the fine DDA can visit there is occupied.  Points are probed every 6 cells (of the smallest cell
 // edge); a cell visited between two probes is < 8 cells (6 + DDA/rounding slop) from the earlier probe
@@ -129,6 +151,12 @@ __device__ __forceinline__ bool segment_clear(const GridSpec &G, int lvl, const 
     // probes are independent: fetch kProbe mask bytes per round trip
     constexpr int kProbe = 4;
     float t = t_a;
+    {   // the first probe alone: a ray standing next to occupied cells is answered after one byte
+        int b[3];
+#pragma unroll
+        for (int a = 0; a < 3; ++a) b[a] = clampi((int)((o[a] + d[a] * fminf(t, t_b) - ab[a]) * inv_ext[a]), 0, G.res - 1) / kBrick;
+        if (mask[(b[0] * G.nb + b[1]) * G.nb + b[2]]) return false;
+    }
     for (;;) {
         uint8_t hit = 0;
 #pragma unroll
@@ -156,8 +184,13 @@ template <class Emit>
 __device__ __forceinline__ int traverse_ray(const GridSpec &G, const float (&o)[3], const float (&d)[3], float near,
                                             float far, const float *__restrict__ ts_row,
                                             const int64_t *__restrict__ ti_row, const uint8_t *__restrict__ hit_row,
-                                            Emit &&emit, float &t_term)
+                                            Emit &&emit, float &t_term
+#ifdef CED_MARCH_PROFILE
+                                            , unsigned long long (&mp_out)[8], unsigned long long &mp_out_t
+#endif
+)
 {
+    CED_MP_DECL
     const float eps = 1e-6f;
     const float inv_d[3] = { 1.0f / d[0], 1.0f / d[1], 1.0f / d[2] };
     const int n_grids = G.n_grids, res = G.res, limit = G.limit;
@@ -166,6 +199,7 @@ __device__ __forceinline__ int traverse_ray(const GridSpec &G, const float (&o)[
     float t_last = near;
     bool continuous = false;
     int n = 0;
+    CED_MP(0)                       // [0] kernel prologue: ray loads
     for (int i = 0; i < 2 * n_grids - 1; ++i) {
         // Sample budget used up: later segments change nothing (the cell loop would not run and
         // `continuous` is true right after an emission), so stop before any early-out can touch state.
@@ -183,7 +217,9 @@ __device__ __forceinline__ int traverse_ray(const GridSpec &G, const float (&o)[
         float this_tmin = fmaxf(ts_row[i], near);
         float this_tmax = fminf(ts_row[i + 1], far);
         if (this_tmin >= this_tmax) continue;
+        CED_MP(1)                   // [1] segment selection
         if (!continuous) t_last = skip_march(t_last, this_tmin, step_size, cone_angle);
+        CED_MP(2)                   // [2] skip-march to the segment start
         const float *ab = G.aabbs + 6 * lvl;
         float tdist[3], delta[3];
         int cur[3], stp[3], ovf[3];
@@ -210,7 +246,9 @@ __device__ __forceinline__ int traverse_ray(const GridSpec &G, const float (&o)[
         // the same step lattice, so any later sample is unchanged; only the termination plane of a ray
         // that ends the call short of `limit` -- a ray that is dead afterwards -- is not advanced.
         const bool can_skip = G.dilated_bricks != nullptr;
-        if (can_skip && segment_clear(G, lvl, o, d, this_tmin, this_tmax)) { continuous = false; continue; }
+        CED_MP(3)                   // [3] DDA set-up
+        if (can_skip && !G.skip_initial_probe && segment_clear(G, lvl, o, d, this_tmin, this_tmax)) { continuous = false; CED_MP(4) continue; }
+        CED_MP(4)                   // [4] brick probes
         int empty_batches = 0;
         // The DDA path does not depend on the occupancy values, so it runs kLook cells ahead and the
         // occupancy bytes of those cells are fetched together.  Runs of empty cells only remember
@@ -248,6 +286,7 @@ __device__ __forceinline__ int traverse_ray(const GridSpec &G, const float (&o)[
                 const bool over = (sx && cur[0] == ovf[0]) || (sy && cur[1] == ovf[1]) || (sz && cur[2] == ovf[2]);
                 dda_done = dda_done || (live && over);
             }
+            CED_MP(5)               // [5] look-ahead DDA
             uint8_t occ[kLook];
 #pragma unroll
             for (int b = 0; b < kLook; ++b) occ[b] = grid[cellv[b]];
@@ -282,16 +321,24 @@ __device__ __forceinline__ int traverse_ray(const GridSpec &G, const float (&o)[
                     if (t_next >= t_trav) break;
                 }
             }
+            CED_MP(6)               // [6] occupancy wait + per-cell emission
             if (can_skip && has_pending && !dda_done && !stop) {
                 // in empty space: every 4th all-empty stretch, ask whether anything is left ahead
                 if ((empty_batches++ & 3) == 0 && segment_clear(G, lvl, o, d, pending, this_tmax)) dda_done = true;
             } else {
                 empty_batches = 0;
             }
+            CED_MP(4)
         }
         if (has_pending) t_last = skip_march(t_last, pending, step_size, cone_angle);
+        CED_MP(2)
     }
     t_term = t_last;
+    CED_MP(1)
+#ifdef CED_MARCH_PROFILE
+    mp_out_t = mp_t;
+    for (int q = 0; q < 8; ++q) mp_out[q] = mp_acc[q];
+#endif
     return n;
 }
 #endif  // __HIPCC__

@@ -1,0 +1,26 @@
+"""Diagnostic (library built with -DCED_MARCH_PROFILE): where the marching kernel's waves spend their cycles,
+per iteration of one 800x800 frame.  usage: CED_NERF_LIB=build/libmprof.so python tools/debug_march_profile.py"""
+import os, sys, ctypes as C
+import numpy as np, torch
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from ced_nerf_amd import _lib, ops, synthetic as S
+from ced_nerf_amd.model import DNGPradianceField
+from ced_nerf_amd.nerfacc_api import OccGridEstimator
+from ced_nerf_amd.utils import Rays, render_image_test
+dev = "cuda:0"; T = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+sc = S.make_scene("dnerf", 800, 800, "trained"); cfg = sc["cfg"]
+f = DNGPradianceField.from_params(sc["params"], dev).eval()
+est = OccGridEstimator(cfg["aabb"], 128, cfg["grid_levels"]).to(dev); est.set_binaries(T(sc["binaries"]))
+rk = dict(sc["render"]); rk["render_bkgd"] = T(rk["render_bkgd"])
+rays = Rays(T(sc["origins"]), T(sc["viewdirs"])); ts = T(sc["timestamps"])
+L = _lib.lib()
+names = ["prologue", "segment select", "skip-march", "DDA set-up", "brick probes", "look-ahead DDA", "occupancy wait + emission", "reserve + copy-out"]
+for max_samples in (1, 2, 4, 7, 11, 17, 26, 41, 71, 132, 1024):      # cumulative: iteration k is the difference
+    buf = (C.c_ulonglong * 16)()
+    L.ced_debug_march_profile(None, 1)
+    render_image_test(max_samples, f, est, rays, timestamps=ts, **rk)
+    torch.cuda.synchronize()
+    L.ced_debug_march_profile(buf, 0)
+    v = np.array(list(buf), np.float64)
+    print(f"max_samples {max_samples:5d}: waves {int(v[8]):6d}  total Mcycles {v[:8].sum()/1e6:8.1f}  " +
+          "  ".join(f"{n} {100*x/max(v[:8].sum(),1):.0f}%" for n, x in zip(names, v[:8])))
