@@ -8,8 +8,10 @@
 //       reference's tiny-cuda-nn FullyFusedMLP (cednerf/model.py:200-222,280-309) and of
 //       BASELINE config 5 ("fp16 hash features + fp16 MFMA MLP").
 //
-// Everything outside the GEMMs (Frequency / SH / time encodings, hash-grid gather and interpolation,
-// trunc_exp, sigmoid, the selector) is the same fp32 code as the exact kernel (field_device.hpp).
+// Outside the GEMMs the encodings (Frequency / SH / time), the hash-grid gather and its interpolation are the
+// same fp32 code as the exact kernel (field_device.hpp), and so is the position normalisation (one ulp there is
+// amplified by the fine hash levels); exp / sigmoid / tanh and the direction normalisation use the hardware's
+// 1-ulp exp2, reciprocal and rsqrt (field_half_device.hpp).
 //
 // Geometry: D^T = W * X^T as in field.hip, but K = 32 per product block (mfma_k32, field_half_device.hpp): lane (g = lane>>4, c = lane&15) supplies
 // inputs 32ks + 8g + e (e = 0..7, four packed VGPRs) of sample c, and receives accumulator rows 4g + r.
@@ -151,13 +153,13 @@ __global__ __launch_bounds__(THREADS) void field_half_kernel(FieldArgs A)
                 if (A.use_div) {
                     constexpr int kFineReg[3] = { 3, 0, 1 };          // rows 3,4,5: (g0,r3), (g1,r0), (g1,r1)
                     const float fine = __shfl(D[j][0][kFineReg[a]], (a == 0) ? c : 16 + c, 64);
-                    const float e = det_expf(2.0f * fine);
-                    const float th = 1.0f - 2.0f / (e + 1.0f);
+                    const float e = fast_exp(2.0f * fine);
+                    const float th = 1.0f - 2.0f * fast_rcp(e + 1.0f);
                     m = m + th * A.moving_step;
                 }
                 mv[a] = m;
                 const float xm = px[j][a] + m;
-                const float x = (xm - A.aabb[a]) / extent[a];
+                const float x = (xm - A.aabb[a]) / extent[a];      // IEEE division: 1 ulp here is amplified by the fine hash levels
                 inside = inside && (x > 0.0f && x < 1.0f);
                 xn[j][a] = __builtin_fminf(__builtin_fmaxf(x, 0.0f), 1.0f);
             }
@@ -219,7 +221,7 @@ __global__ __launch_bounds__(THREADS) void field_half_kernel(FieldArgs A)
 #pragma unroll
         for (int j = 0; j < NT; ++j) {
             const int64_t s = tile * TILE + 16 * j + c;
-            float sg = det_expf(D[j][0][3] - 1.0f);            // trunc_exp(raw - 1) * selector
+            float sg = fast_exp(D[j][0][3] - 1.0f);            // trunc_exp(raw - 1) * selector
             sg = sel[j] ? sg : 0.0f;
             if (g == 3 && s < n_eff) A.sigma[s] = sg;
             if (A.geo && s < n_eff) {
@@ -237,11 +239,11 @@ __global__ __launch_bounds__(THREADS) void field_half_kernel(FieldArgs A)
 #pragma unroll
                 for (int a = 0; a < 3; ++a)
                     dv[a] = A.rays_mode ? A.rays_d[3 * ridx[j] + a] : A.dir[3 * sidx[j] + a];
-                const float nrm = __builtin_sqrtf((dv[0] * dv[0] + dv[1] * dv[1]) + dv[2] * dv[2]);
+                const float inv_nrm = __builtin_amdgcn_rsqf((dv[0] * dv[0] + dv[1] * dv[1]) + dv[2] * dv[2]);
                 float v[3];
 #pragma unroll
                 for (int a = 0; a < 3; ++a) {
-                    const float u = (dv[a] / nrm + 1.0f) / 2.0f;
+                    const float u = (dv[a] * inv_nrm + 1.0f) / 2.0f;
                     v[a] = u * 2.0f - 1.0f;
                 }
                 float sh = 0.28209479177387814f;
@@ -266,7 +268,7 @@ __global__ __launch_bounds__(THREADS) void field_half_kernel(FieldArgs A)
                 const int64_t s = tile * TILE + 16 * j + c;
                 float o3[3];
 #pragma unroll
-                for (int a = 0; a < 3; ++a) o3[a] = 1.0f / (1.0f + det_expf(-D[j][0][a]));
+                for (int a = 0; a < 3; ++a) o3[a] = fast_rcp(1.0f + fast_exp(-D[j][0][a]));
                 if (g == 0 && s < n_eff) {
                     A.rgb[3 * s] = o3[0];
                     A.rgb[3 * s + 1] = o3[1];

@@ -28,6 +28,12 @@ constexpr float kHalfMax = 65504.0f;
 #define CED_HALF_MFMA_GUARD 3
 #endif
 
+// Elementwise math of the half-precision kernels: the hardware's 1-ulp exp2 / reciprocal / rsqrt instead of the
+// exact kernel's deterministic polynomials and IEEE divisions (those exist to match the oracle bit for bit, which
+// these modes do not attempt; the differences are ~1e-7 relative, far below the fp16 operand rounding).
+__device__ __forceinline__ float fast_exp(float x) { return __builtin_amdgcn_exp2f(x * 1.44269504088896340736f); }
+__device__ __forceinline__ float fast_rcp(float x) { return __builtin_amdgcn_rcpf(x); }
+
 // eight fp32 values -> packed fp16 operand (and the fp16 remainder in F16X2 mode)
 template <bool SPLIT> __device__ __forceinline__ void to_half8(const float (&v)[8], h8 &hi, h8 &lo)
 {
