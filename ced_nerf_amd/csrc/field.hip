@@ -441,6 +441,89 @@ __global__ __launch_bounds__(256) void hash_encode_kernel(HashArgs A)
     }
 }
 
+// ---- backward of the (non-temporal) hash encode: next row f2, training path ---------------------------
+// One lane per (sample, level) as in hash_encoder_half.py:164-226.  Table gradient: one hardware fp32 atomic add
+// per corner and feature (the reference's `hash_grad[index] += w * dL/dy`).  As in the reference the position
+// gradient is w.r.t. the scaled position (no `scale` factor), and levels whose dL/dy is all zero are skipped.
+struct HashBwdArgs {
+    int64_t n;
+    const float *x, *dy;
+    float *grad_table, *dx;
+    int n_levels, table_dtype;
+    const void *table;
+    float scale[CED_MAX_LEVELS];
+    uint32_t res[CED_MAX_LEVELS], offset[CED_MAX_LEVELS], size[CED_MAX_LEVELS], hashed[CED_MAX_LEVELS];
+};
+
+// LEVEL_MAJOR: blockIdx.y = level, consecutive lanes = consecutive samples -- a wave's atomics then fall into one
+// level's region and, for ray-ordered samples, into few cache lines (used for the table gradient).  Otherwise 16
+// consecutive lanes = the 16 levels of one sample, whose position-gradient contributions are summed inside the
+// 16-lane group in a fixed order and stored without atomics (used for dx).
+template <bool F16, bool LEVEL_MAJOR>
+__global__ __launch_bounds__(256) void hash_backward_kernel(HashBwdArgs A)
+{
+    const int64_t gid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int64_t i = LEVEL_MAJOR ? gid : (gid >> 4);
+    const int l = LEVEL_MAJOR ? (int)blockIdx.y : (int)(gid & 15);
+    float gx[3] = { 0.0f, 0.0f, 0.0f };
+    if (i < A.n && l < A.n_levels) {
+        const float g0 = A.dy[(i * A.n_levels + l) * 2], g1 = A.dy[(i * A.n_levels + l) * 2 + 1];
+        if (g0 != 0.0f || g1 != 0.0f) {
+            const float sc = A.scale[l];
+            uint32_t g[3];
+            float fr[3], om[3];
+#pragma unroll
+            for (int a = 0; a < 3; ++a) {
+                const float xa = __builtin_fminf(__builtin_fmaxf(A.x[3 * i + a], 0.0f), 1.0f);
+                const float pos = xa * sc + 0.5f;
+                const float fl = __builtin_floorf(pos);
+                g[a] = (uint32_t)fl;
+                fr[a] = pos - fl;
+                om[a] = 1.0f - fr[a];
+            }
+            const uint32_t res = A.res[l], size = A.size[l], off = A.offset[l];
+            const bool hashed = A.hashed[l] != 0;
+#pragma unroll
+            for (int c = 0; c < 8; ++c) {
+                const uint32_t px = g[0] + (c & 1), py = g[1] + ((c >> 1) & 1), pz = g[2] + ((c >> 2) & 1);
+                const float wx = (c & 1) ? fr[0] : om[0], wy = (c & 2) ? fr[1] : om[1], wz = (c & 4) ? fr[2] : om[2];
+                const float w = (wx * wy) * wz;
+                uint32_t idx = hashed ? (px ^ (py * 2654435761u) ^ (pz * 805459861u)) : (px + py * res + pz * res * res);
+                idx = off + idx % size;
+                if constexpr (!LEVEL_MAJOR) {
+                    float f0, f1;
+                    if constexpr (!F16) {
+                        const float2 v = reinterpret_cast<const float2 *>(A.table)[idx];
+                        f0 = v.x; f1 = v.y;
+                    } else {
+                        const uint32_t u = reinterpret_cast<const uint32_t *>(A.table)[idx];
+                        f0 = half_bits_to_float((uint16_t)(u & 0xffffu)); f1 = half_bits_to_float((uint16_t)(u >> 16));
+                    }
+                    // d w / d pos_a = +-(product of the other two factors)
+                    const float dot = f0 * g0 + f1 * g1;
+                    gx[0] += dot * ((c & 1) ? (wy * wz) : -(wy * wz));
+                    gx[1] += dot * ((c & 2) ? (wx * wz) : -(wx * wz));
+                    gx[2] += dot * ((c & 4) ? (wx * wy) : -(wx * wy));
+                } else {
+                    unsafeAtomicAdd(A.grad_table + (size_t)idx * 2, w * g0);
+                    unsafeAtomicAdd(A.grad_table + (size_t)idx * 2 + 1, w * g1);
+                }
+            }
+        }
+    }
+    if constexpr (!LEVEL_MAJOR) {
+        // sum over the 16 levels of the sample (lanes 16k..16k+15), fixed order
+#pragma unroll
+        for (int off = 8; off > 0; off >>= 1) {
+#pragma unroll
+            for (int a = 0; a < 3; ++a) gx[a] += __shfl_down(gx[a], off, 16);
+        }
+        if (l == 0 && i < A.n) {
+            A.dx[3 * i] = gx[0]; A.dx[3 * i + 1] = gx[1]; A.dx[3 * i + 2] = gx[2];
+        }
+    }
+}
+
 int g_field_stagger = 0;          // field kernel: start-up phase offset between the waves of a SIMD, in s_sleep(127) units
 int g_field_spread_tiles = 1;     // field kernels: deal tiles across all CUs first (ced_set_option)
 bool g_march_early_out = true;    // frame renderer: conservative brick-level early-out (ced_set_option)
@@ -698,4 +781,33 @@ extern "C" int ced_hash_encode(const ced_hash_desc *desc, int64_t n, const float
     default: hipLaunchKernelGGL((ced::hash_encode_kernel<true, true>), grid, block, 0, (hipStream_t)stream, A); break;
     }
     return ced::check_launch("hash_encode");
+}
+
+extern "C" int ced_hash_encode_backward(const ced_hash_desc *desc, int64_t n, const float *x, const float *dy,
+                                        float *grad_table, float *dx, void *stream)
+{
+    int rc = ced::validate_hash(desc, "hash_encode_backward");
+    if (rc) return rc;
+    CED_REQUIRE(n >= 0, "hash_encode_backward: n < 0");
+    CED_REQUIRE(!desc->temporal, "hash_encode_backward: the temporal table has no backward yet");
+    CED_REQUIRE(desc->n_levels <= 16, "hash_encode_backward: n_levels > 16");
+    if (n == 0) return CED_OK;
+    CED_REQUIRE(x && dy && grad_table, "hash_encode_backward: null pointer");
+    ced::HashBwdArgs A{};
+    A.n = n; A.x = x; A.dy = dy; A.grad_table = grad_table; A.dx = dx;
+    A.n_levels = desc->n_levels; A.table_dtype = desc->table_dtype; A.table = desc->table;
+    for (int l = 0; l < CED_MAX_LEVELS; ++l) {
+        A.scale[l] = desc->scale[l]; A.res[l] = desc->res[l]; A.offset[l] = desc->offset[l];
+        A.size[l] = desc->size[l]; A.hashed[l] = desc->hashed[l];
+    }
+    const dim3 block(256);
+    // table gradient: level-major; position gradient (optional): sample-major, no atomics
+    const dim3 grid_t((unsigned)((n + 255) / 256), (unsigned)desc->n_levels);
+    hipLaunchKernelGGL((ced::hash_backward_kernel<false, true>), grid_t, block, 0, (hipStream_t)stream, A);
+    if (dx) {
+        const dim3 grid_x((unsigned)((n * 16 + 255) / 256));
+        if (A.table_dtype) hipLaunchKernelGGL((ced::hash_backward_kernel<true, false>), grid_x, block, 0, (hipStream_t)stream, A);
+        else hipLaunchKernelGGL((ced::hash_backward_kernel<false, false>), grid_x, block, 0, (hipStream_t)stream, A);
+    }
+    return ced::check_launch("hash_encode_backward");
 }

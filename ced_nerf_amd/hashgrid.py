@@ -10,6 +10,7 @@ from __future__ import annotations
 from typing import Dict
 
 import numpy as np
+import torch
 
 MAX_LEVELS = 16
 
@@ -45,3 +46,58 @@ def level_tables(base_res: int = 16, max_res: int = 1024, n_levels: int = 16,
         raise ValueError("hash table too large for 32-bit entry indices")
     return dict(n_levels=n_levels, scale=scale, res=res, offset=offset, size=size, hashed=hashed,
                 total=running, log2_hashmap_size=int(log2_hashmap_size))
+
+
+
+class HashEncoder(torch.nn.Module):
+    """Trainable multi-resolution hash grid with the interface of the reference's `HashEncoder`
+    (cednerf/taichi_kernel/hash_encoder_half.py:231-385): `forward(positions [N,3] in [0,1]) -> [N, levels*2]`,
+    parameters in `hash_table [E,2]` (uniform +-1e-4, :313), gradients for the table and the positions through the
+    HIP kernels ced_hash_encode / ced_hash_encode_backward.  `max_params` is the per-level cap (2**log2_hashmap_size).
+    First piece of the training path."""
+
+    def __init__(self, max_params: float = 2 ** 19, levels: int = 16, base_res: float = 16.0, max_res: float = 2048.0,
+                 feature_per_level: int = 2, device="cuda"):
+        super().__init__()
+        if feature_per_level != 2:
+            raise NotImplementedError("the HIP hash grid stores 2 features per entry")
+        log2T = int(round(np.log2(max_params)))
+        if 2 ** log2T != int(max_params):
+            raise ValueError("max_params must be a power of two")
+        self.cfg = dict(n_levels=int(levels), max_res=int(max_res), base_res=int(base_res), log2_hashmap_size=log2T)
+        tabs = level_tables(int(base_res), int(max_res), int(levels), log2T)
+        self.hash_level = int(levels)
+        self.out_dim = self.n_output_dims = 2 * int(levels)
+        self.begin_fast_hash_level = int(np.argmax(tabs["hashed"])) if tabs["hashed"].any() else int(levels)
+        table = torch.empty((tabs["total"], 2), dtype=torch.float32, device=device).uniform_(-1e-4, 1e-4)
+        self.hash_table = torch.nn.Parameter(table, requires_grad=True)
+
+    def _desc(self, table):
+        from . import ops
+        d, _ = ops.make_hash_desc(table, self.cfg["base_res"], self.cfg["max_res"], self.cfg["n_levels"],
+                                  self.cfg["log2_hashmap_size"], False)
+        return d
+
+    def forward(self, positions: torch.Tensor) -> torch.Tensor:
+        return _HashEncodeFunction.apply(positions.reshape(-1, 3).float().contiguous(), self.hash_table, self)
+
+
+class _HashEncodeFunction(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, table, module):
+        from . import ops
+        if x.device.type != "cuda":
+            raise NotImplementedError("Only support cuda inputs.")
+        tab = table.detach().contiguous()
+        out = ops.hash_encode(module._desc(tab), x.detach())
+        ctx.save_for_backward(x.detach(), tab)
+        ctx.module = module
+        return out
+
+    @staticmethod
+    def backward(ctx, dy):
+        from . import ops
+        x, tab = ctx.saved_tensors
+        grad_table, dx = ops.hash_encode_backward(ctx.module._desc(tab), x, dy.float().contiguous(),
+                                                  want_dx=ctx.needs_input_grad[0])
+        return dx, grad_table, None

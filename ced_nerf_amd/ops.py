@@ -148,6 +148,23 @@ def hash_encode(desc: _lib.HashDesc, x: torch.Tensor, t: Optional[torch.Tensor] 
     return out
 
 
+def hash_encode_backward(desc: _lib.HashDesc, x: torch.Tensor, dy: torch.Tensor,
+                         grad_table: Optional[torch.Tensor] = None, want_dx: bool = True):
+    """ced_hash_encode_backward: (grad_table [E,2] fp32 -- accumulated into when given, else fresh --, dx [n,3] or None)."""
+    _chk(x, torch.float32, "x"); _chk(dy, torch.float32, "dy")
+    n = x.shape[0]
+    assert x.shape == (n, 3) and dy.numel() == n * 2 * desc.n_levels, f"{x.shape} v.s. {dy.shape}"
+    if grad_table is None:
+        grad_table = torch.zeros((int(desc.total_entries), 2), device=x.device, dtype=torch.float32)
+    else:
+        _chk(grad_table, torch.float32, "grad_table")
+        assert grad_table.shape == (int(desc.total_entries), 2)
+    dx = torch.empty((n, 3), device=x.device, dtype=torch.float32) if want_dx else None
+    rc = _lib.lib().ced_hash_encode_backward(C.byref(desc), n, _p(x), _p(dy), _p(grad_table), _p(dx), _stream())
+    _lib.check(rc, "hash_encode_backward")
+    return grad_table, dx
+
+
 def field_forward(desc: _lib.FieldDesc, positions, t, directions=None, want_geo=False):
     _chk(positions, torch.float32, "positions"); _chk(t, torch.float32, "t")
     n = positions.shape[0]

@@ -156,6 +156,14 @@ float ced_host_skip_march(float t_last, float target, float step_size, float con
 int ced_hash_encode(const ced_hash_desc *desc, int64_t n, const float *x, const float *t,
                     float *out, void *stream);
 
+/* Backward of ced_hash_encode (non-temporal tables): the training-path row of SURVEY 8f, restating
+ * hash_encoder_backward_kernel, taichi_kernel/hash_encoder_half.py:164-226.  dy [n, 2*n_levels] is the gradient
+ * w.r.t. the encoder output; grad_table [total_entries, 2] fp32 is ACCUMULATED into (one hardware atomic add per
+ * corner and feature; zero it first for a fresh gradient, as HashEncoder.backward does at :362-364); dx [n, 3]
+ * (optional) receives the position gradient, w.r.t. the scaled position as in the reference (no `scale` factor). */
+int ced_hash_encode_backward(const ced_hash_desc *desc, int64_t n, const float *x, const float *dy,
+                             float *grad_table, float *dx, void *stream);
+
 /* DNGPradianceField.forward(positions, t, directions) -- cednerf/model.py:468-488 (query_move
  * :354-365, query_density :367-445, _query_rgb :447-466), fused into one kernel.
  * dir/rgb may both be NULL (density only = query_density, model.py:367); geo [n,15] may be NULL

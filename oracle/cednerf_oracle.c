@@ -429,6 +429,59 @@ void ced_o_hash_encode(const ced_o_hash_t *h, int64_t n, const float *x, const f
         hash_encode_one(h, x + 3 * i, t ? t[i] : 0.0f, out + (int64_t)2 * h->n_levels * i);
 }
 
+/* Backward of the (non-temporal) hash encode, hash_encoder_half.py:164-226 (next row f2: training path).
+ *   dy [n][L][2]          gradient w.r.t. the encoder output
+ *   grad_table [E][2]     += w * dy per corner (accumulated here in DOUBLE, in sample/level/corner order: the
+ *                         reference adds with atomics in no particular order, so only the sum is specified)
+ *   dx [n][3] (optional)  = sum over levels and corners of (table_feat . dy) * dw/dpos, with the reference's
+ *                         form dw/dpos_d = w / (+-other factor) (:212-213) and, like the reference, WITHOUT
+ *                         the d pos / d x = scale factor. */
+void ced_o_hash_encode_backward(const ced_o_hash_t *h, int64_t n, const float *x_in, const float *dy,
+                                double *grad_table, float *dx)
+{
+    for (int64_t i = 0; i < n; ++i) {
+        float x[3];
+        for (int a = 0; a < 3; ++a) x[a] = fminf(fmaxf(x_in[3 * i + a], 0.0f), 1.0f);
+        float gx[3] = { 0.0f, 0.0f, 0.0f };
+        for (int l = 0; l < h->n_levels; ++l) {
+            const float sc = h->scale[l];
+            const float g0 = dy[(i * h->n_levels + l) * 2], g1 = dy[(i * h->n_levels + l) * 2 + 1];
+            uint32_t g[3];
+            float fr[3], om[3];
+            for (int a = 0; a < 3; ++a) {
+                float pos = x[a] * sc + 0.5f;
+                float fl = floorf(pos);
+                g[a] = (uint32_t)fl;
+                fr[a] = pos - fl;
+                om[a] = 1.0f - fr[a];
+            }
+            if (g0 == 0.0f && g1 == 0.0f) continue;                       /* grad_dy_temp.any(), :209 */
+            for (int c = 0; c < 8; ++c) {
+                float w = 1.0f, dwd[3];
+                uint32_t p[3];
+                for (int a = 0; a < 3; ++a) {
+                    if ((c & (1 << a)) == 0) { p[a] = g[a]; w = w * om[a]; dwd[a] = -om[a]; }
+                    else { p[a] = g[a] + 1u; w = w * fr[a]; dwd[a] = fr[a]; }
+                }
+                const uint32_t idx = h->offset[l] + grid_index(h, l, p[0], p[1], p[2]);
+                float f0, f1;
+                if (h->table_dtype == 0) {
+                    const float *tb = (const float *)h->table + (size_t)idx * 2;
+                    f0 = tb[0]; f1 = tb[1];
+                } else {
+                    const uint16_t *tb = (const uint16_t *)h->table + (size_t)idx * 2;
+                    f0 = half_to_float(tb[0]); f1 = half_to_float(tb[1]);
+                }
+                const float dot = f0 * g0 + f1 * g1;
+                if (dx) for (int a = 0; a < 3; ++a) gx[a] = gx[a] + dot * (w / dwd[a]);
+                grad_table[(size_t)idx * 2] += (double)(w * g0);
+                grad_table[(size_t)idx * 2 + 1] += (double)(w * g1);
+            }
+        }
+        if (dx) for (int a = 0; a < 3; ++a) dx[3 * i + a] = gx[a];
+    }
+}
+
 /* corner entry indices (into the table, offset included) of level l for a point: exposed so
  * tests can check the integer part of the lookup bit-exactly. */
 void ced_o_hash_indices(const ced_o_hash_t *h, int64_t n, const float *x_in, uint32_t *idx /* [n][L][8] */)

@@ -133,6 +133,76 @@ def test_hash_encode(oracle, max_res, log2T, dtype, temporal):
     assert np.abs(want).max() > 0.1
 
 
+@pytest.mark.parametrize("max_res,log2T,dtype", [(1024, 17, np.float32), (4096, 15, np.float16), (256, 19, np.float32)])
+def test_hash_encode_backward(oracle, max_res, log2T, dtype):
+    """SURVEY 8f row 2, first piece: hash_encoder_backward_kernel (hash_encoder_half.py:164-226).  The table gradient
+    is a sum of atomic adds in no particular order, so it is compared with the oracle's double-precision sum to fp32
+    rounding noise; zero output-gradient levels are skipped as in the reference; the position gradient follows the
+    reference's w / (d w) form, compared away from the cell faces where that form divides by ~0."""
+    from ced_nerf_amd import ops, synthetic as S
+    p = S.init_field_params([-1, -1, -1, 1, 1, 1], 1e-4, max_res, log2T, regime="trained", table_dtype=dtype)
+    of = oracle.OracleField({"hash": p["hash"]})
+    n = 30000
+    x = _points(n, 5)[:n]
+    rng = np.random.default_rng(6)
+    dy = rng.normal(size=(x.shape[0], 32)).astype(np.float32)
+    dy[::7, 4:6] = 0.0                                   # some all-zero levels (skipped, :209)
+    dy[3] = 0.0
+    want_grad, want_dx = of.hash_encode_backward(x, dy)
+    table = T(p["hash"]["table"])
+    desc, _ = ops.make_hash_desc(table, 16, max_res, 16, log2T, False)
+    grad, dx = ops.hash_encode_backward(desc, T(x), T(dy))
+    g = N(grad).astype(np.float64)
+    scale = np.abs(want_grad).max()
+    assert scale > 1.0
+    # fp32 atomic sums of up to ~1e3 terms: error ~ sqrt(terms) * eps * magnitude
+    assert np.abs(g - want_grad).max() <= 2e-5 * scale, np.abs(g - want_grad).max() / scale
+    assert np.array_equal(g == 0, want_grad == 0)         # exactly the entries the oracle touches
+    # accumulation into an existing gradient
+    grad2, _ = ops.hash_encode_backward(desc, T(x), T(dy), grad_table=grad.clone(), want_dx=False)
+    assert np.abs(N(grad2).astype(np.float64) - 2 * want_grad).max() <= 4e-5 * scale
+    # position gradient: away from cell faces (every level's fractional position in [0.02, 0.98])
+    lv = of.levels
+    frac = (np.clip(x, 0, 1)[:, None, :] * lv["scale"][:16, None].astype(np.float32) + np.float32(0.5)) % 1.0
+    interior = ((frac > 0.02) & (frac < 0.98)).all(axis=(1, 2))
+    assert interior.sum() > 100
+    d_err = np.abs(N(dx)[interior] - want_dx[interior]).max() / np.abs(want_dx[interior]).max()
+    assert d_err <= 1e-4, d_err
+    # duality (size-independent property): the forward is linear in the table, so for any table perturbation dT
+    # <dy, encode(T + dT) - encode(T)> == <grad_table, dT>
+    if dtype == np.float32:
+        dT = torch.randn_like(table) * 0.1
+        d2, _ = ops.make_hash_desc((table + dT).contiguous(), 16, max_res, 16, log2T, False)
+        t2 = (table + dT).contiguous()
+        d2, _ = ops.make_hash_desc(t2, 16, max_res, 16, log2T, False)
+        lhs = ((ops.hash_encode(d2, T(x)) - ops.hash_encode(desc, T(x))).double() * T(dy).double()).sum().item()
+        rhs = (grad.double() * dT.double()).sum().item()
+        assert abs(lhs - rhs) <= 2e-4 * max(abs(lhs), abs(rhs), 1.0), (lhs, rhs)
+
+
+def test_trainable_hash_encoder_module(oracle):
+    """The reference-shaped `HashEncoder` module (hash_encoder_half.py:231-385) on the HIP kernels: a few SGD steps on
+    a regression target reduce the loss, and autograd's gradients are the kernels' gradients."""
+    from ced_nerf_amd.hashgrid import HashEncoder
+    torch.manual_seed(0)
+    enc = HashEncoder(max_params=2 ** 15, levels=16, base_res=16, max_res=512, device=DEV)
+    assert enc.n_output_dims == 32 and enc.hash_table.shape[1] == 2
+    x = torch.rand(4096, 3, device=DEV, requires_grad=True)
+    target = torch.sin(x.detach().sum(dim=1, keepdim=True) * 6.0).expand(-1, 32) * 0.1
+    opt = torch.optim.Adam(enc.parameters(), lr=1e-2)
+    losses = []
+    for _ in range(40):
+        opt.zero_grad()
+        y = enc(x)
+        loss = ((y - target) ** 2).mean()
+        loss.backward()
+        opt.step()
+        losses.append(loss.item())
+    assert losses[-1] < 0.5 * losses[0], losses[::6]
+    assert x.grad is not None and torch.isfinite(x.grad).all() and x.grad.abs().max() > 0
+    assert enc.hash_table.grad.shape == enc.hash_table.shape
+
+
 FIELD_CASES = [
     dict(), dict(use_div_offsets=True), dict(use_time_embedding=True),
     dict(use_time_embedding=True, use_time_attenuation=True, use_div_offsets=True),
