@@ -463,9 +463,16 @@ template <bool F16, bool LEVEL_MAJOR>
 __global__ __launch_bounds__(256) void hash_backward_kernel(HashBwdArgs A)
 {
     const int64_t gid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    const int64_t i = LEVEL_MAJOR ? gid : (gid >> 4);
+    // LEVEL_MAJOR: two adjacent lanes = the two features of one sample's entries, so one atomic instruction covers
+    // 32 entries x 2 adjacent dwords (half the cache-line requests of 64 entries x 1 dword, twice)
+    const int64_t i = LEVEL_MAJOR ? (gid >> 1) : (gid >> 4);
+    const int feat = (int)(gid & 1);
     const int l = LEVEL_MAJOR ? (int)blockIdx.y : (int)(gid & 15);
     float gx[3] = { 0.0f, 0.0f, 0.0f };
+    uint32_t pend_idx[8];
+    float pend_val[8];
+#pragma unroll
+    for (int c = 0; c < 8; ++c) { pend_idx[c] = 0xffffffffu; pend_val[c] = 0.0f; }
     if (i < A.n && l < A.n_levels) {
         const float g0 = A.dy[(i * A.n_levels + l) * 2], g1 = A.dy[(i * A.n_levels + l) * 2 + 1];
         if (g0 != 0.0f || g1 != 0.0f) {
@@ -505,10 +512,32 @@ __global__ __launch_bounds__(256) void hash_backward_kernel(HashBwdArgs A)
                     gx[1] += dot * ((c & 2) ? (wx * wz) : -(wx * wz));
                     gx[2] += dot * ((c & 4) ? (wx * wy) : -(wx * wy));
                 } else {
-                    unsafeAtomicAdd(A.grad_table + (size_t)idx * 2, w * g0);
-                    unsafeAtomicAdd(A.grad_table + (size_t)idx * 2 + 1, w * g1);
+                    pend_idx[c] = idx;
+                    pend_val[c] = w * (feat ? g1 : g0);
                 }
             }
+        }
+    }
+    if constexpr (LEVEL_MAJOR) {
+        // Consecutive samples of a ray sit in the same cell of the coarse and middle levels: sum the runs of equal
+        // entries across the wave first (segmented scan over same-feature lanes, stride 2) and let the last lane of
+        // a run issue ONE atomic -- the atomics are what bounds this kernel (one L2 request per cache line touched).
+        const int lane = threadIdx.x & 63;
+#pragma unroll
+        for (int c = 0; c < 8; ++c) {
+            const uint32_t idx = pend_idx[c];
+            float v = pend_val[c];
+            const uint32_t prev = __shfl_up(idx, 2, 64);
+            int head = (lane < 2 || prev != idx) ? 1 : 0;
+#pragma unroll
+            for (int d = 2; d < 64; d <<= 1) {
+                const float v_up = __shfl_up(v, d, 64);
+                const int h_up = __shfl_up(head, d, 64);
+                if (lane >= d && !head) { v += v_up; head |= h_up; }
+            }
+            const uint32_t next = __shfl_down(idx, 2, 64);
+            const bool last = lane >= 62 || next != idx;
+            if (last && idx != 0xffffffffu && v != 0.0f) unsafeAtomicAdd(A.grad_table + (size_t)idx * 2 + feat, v);
         }
     }
     if constexpr (!LEVEL_MAJOR) {
@@ -802,7 +831,7 @@ extern "C" int ced_hash_encode_backward(const ced_hash_desc *desc, int64_t n, co
     }
     const dim3 block(256);
     // table gradient: level-major; position gradient (optional): sample-major, no atomics
-    const dim3 grid_t((unsigned)((n + 255) / 256), (unsigned)desc->n_levels);
+    const dim3 grid_t((unsigned)((2 * n + 255) / 256), (unsigned)desc->n_levels);
     hipLaunchKernelGGL((ced::hash_backward_kernel<false, true>), grid_t, block, 0, (hipStream_t)stream, A);
     if (dx) {
         const dim3 grid_x((unsigned)((n * 16 + 255) / 256));
