@@ -109,11 +109,18 @@ def main():
     if args.gpus != world:
         if world == 1 and args.gpus > 1:
             raise SystemExit("launch multi-GPU runs with torch.distributed.run (one process per GPU)")
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
+    # one rank per GPU; CED_BENCH_BACKEND=gloo is the rehearsal mode (several ranks may then share one card, and
+    # the pixel gather is staged through the host: ced_nerf_amd/dist.py)
+    backend = os.environ.get("CED_BENCH_BACKEND", "nccl")
+    dev_index = local_rank % max(torch.cuda.device_count(), 1)
+    torch.cuda.set_device(dev_index)
+    dev = torch.device("cuda", dev_index)
     import torch.distributed as dist
     if world > 1:
-        dist.init_process_group("nccl", device_id=dev)
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev)
+        else:
+            dist.init_process_group(backend)
 
     from ced_nerf_amd import _lib, synthetic as S
     from ced_nerf_amd import dist as cdist
@@ -253,7 +260,7 @@ def main():
     single_field = {"ms": 0.0, "launches": 0, "units": 0.0}
     lane_renderers[0].tracer = tracers[0][0]
     for _ in range(5):
-        lane_renderers[0].render(ts)
+        lane_renderers[0].render_local(ts)          # this rank's shard only: the other ranks have left by now
         ms = tracers[0][0].field_ms()
         single_field["ms"] += sum(ms); single_field["launches"] += len(ms)
         single_field["units"] += float(sum(it["n_new"] for it in tracers[0][0].iterations()))

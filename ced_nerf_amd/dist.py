@@ -121,7 +121,13 @@ class ShardedRenderer:
         payload[-1, 0] = float(n_samples >> 16)          # exact in float32: two 16-bit halves
         payload[-1, 1] = float(n_samples & 0xFFFF)
         gathered = torch.empty((self.world, self.n_pad + 1, 5), device=rgb.device, dtype=torch.float32)
-        dist.all_gather_into_tensor(gathered.view(-1, 5), payload)
+        if payload.is_cuda and dist.get_backend() == "gloo":
+            # rehearsal of the multi-rank path without RCCL (ranks sharing one card): stage through the host
+            parts = [torch.empty((self.n_pad + 1, 5), dtype=torch.float32) for _ in range(self.world)]
+            dist.all_gather(parts, payload.cpu())
+            gathered.copy_(torch.stack(parts))
+        else:
+            dist.all_gather_into_tensor(gathered.view(-1, 5), payload)
         tail = gathered[:, -1, :2].to(torch.float64)
         total_t = (tail[:, 0] * 65536.0 + tail[:, 1]).sum()
         total = int(total_t.item()) if sync_total else None

@@ -877,3 +877,23 @@ def test_frame_renderer_edge_cases(oracle):
         render_image_test(8, f, est, Rays(T(o), T(d)), timestamps=None)
     with pytest.raises(NotImplementedError, match="cuda"):
         render_image_test(8, f, est, Rays(torch.from_numpy(o), torch.from_numpy(d)), timestamps=ts)
+
+
+def test_bench_two_rank_rehearsal():
+    """bench.py's multi-rank path end to end (launch line of the driver, 2 ranks): sharding, frames in flight, the
+    asynchronous pixel gather, the other precision modes, rank 0's JSON line.  The ranks share this box's one card, so
+    the collective runs over gloo staged through the host (CED_BENCH_BACKEND=gloo); with RCCL only that call differs."""
+    import json, os, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, CED_BENCH_BACKEND="gloo")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", "29517", os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1",
+           "--width", "256", "--height", "256", "--no-cpu-baseline", "--also", "f16x2"]
+    out = subprocess.run(cmd, cwd=root, env=env, capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, out.stdout[-2000:]
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["steps"] == 2 and d["scaling"] == "weak" and d["value"] > 0
+    assert d["config"]["frames_per_step"] == 6 and "f16x2" in d["other_mlp_precisions"]
+    assert d["roofline"]["bound"] == "mfma" and 0 < d["roofline"]["frac"] < 1
