@@ -50,9 +50,11 @@ typedef _Float16 h4 __attribute__((ext_vector_type(4)));
 // One K = 32 product block of D^T = W * X^T.  gfx950's v_mfma_f32_16x16x32_f16 does it in one instruction,
 // but under ROCm 7.2 kernels built on it were NOT reproducible on MI355X: with two or three waves per SIMD about
 // 0.2 % of the 16-sample tiles came out wrong, different ones on every run, always the tile whose MFMA is the last
-// reader of the group's A operand.  Scheduler fences and s_nop pads around the MFMA groups and pinning the operand
-// registers moved the failure between the f16x2 and f16 variants but never removed it from both
-// (tools/debug_half.py is the reproducer; define CED_HALF_MFMA_K32 to build that form).  The same block issued as
+// reader of the group's A operand.  It is not a software-visible hazard: scheduler fences and s_nop pads around
+// the MFMA groups and pinning the operand registers moved the failure between the f16x2 and f16 variants but
+// never removed it from both, and with EVERY such MFMA fenced, padded before and after and its operands pinned
+// the kernels were still irreproducible -- more so the longer the pads, i.e. the more other waves' MFMAs got in
+// between (tools/debug_half.py is the reproducer; define CED_HALF_MFMA_K32 to build that form).  The same block issued as
 // two v_mfma_f32_16x16x16_f16 over the low / high four halves of each lane's operands -- the same index pairing,
 // hence the same sum, no data movement -- is reproducible over repeated 15 M-sample launches in both variants, and
 // is what ships (f16x2: 3.6 instead of 4.2 Gsamples/s; f16: 5.1 either way).
