@@ -75,6 +75,7 @@ PROTOTYPES = {
     "ced_accumulate_along_rays": (C.c_int, [_i64, _vp, _vp, _vp, _i32, _vp, _vp]),
     "ced_visibility_mask": (C.c_int, [_i64, _vp, _vp, _vp, _vp, _f, _f, _vp, _vp]),
     "ced_composite_prefix": (C.c_int, [_i64, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "ced_composite_backward": (C.c_int, [_i64, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "ced_composite_step": (C.c_int, [_i64, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _f, _i32, _vp, _vp, _vp]),
     "ced_composite_test": (C.c_int, [_i64, _vp, _vp, _vp, _vp, _vp, _vp, _f, _f, _vp, _vp, _vp, _vp]),
     "ced_finalize_pixels": (C.c_int, [_i64, _vp, _vp, _vp, _vp, _vp]),

@@ -211,6 +211,64 @@ __global__ __launch_bounds__(256) void finalize_kernel(int64_t n_rays, const flo
 
 static inline dim3 grid_for(int64_t n) { return dim3((unsigned)((n + 255) / 256)); }
 
+// Backward of the training-time compositing: d(colors, opacities, depths)/d(sigmas, rgbs) of
+// cednerf/render.py:158-169.  One lane per ray, two sweeps: forward for the total optical depth, then backward
+// with the suffix sum S_i = sum_{k>i} g_k w_k:
+//   g_i = <d_color, rgb_i> + d_opacity + d_depth * t_mid_i,   d rgb_i = w_i d_color,
+//   d sigma_i = dt_i * (g_i (T_i - w_i) - S_i).
+__global__ __launch_bounds__(256) void composite_backward_kernel(int64_t n_rays, const int64_t *__restrict__ packed,
+                                                                 const float *__restrict__ t0, const float *__restrict__ t1,
+                                                                 const float *__restrict__ sig, const float *__restrict__ rgbs,
+                                                                 const float *__restrict__ d_color,
+                                                                 const float *__restrict__ d_opacity,
+                                                                 const float *__restrict__ d_depth,
+                                                                 float *__restrict__ d_sig, float *__restrict__ d_rgbs)
+{
+    const int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= n_rays) return;
+    const int64_t s0 = packed[2 * r], cnt = packed[2 * r + 1];
+    if (cnt <= 0) return;
+    const float dc0 = d_color[3 * r], dc1 = d_color[3 * r + 1], dc2 = d_color[3 * r + 2];
+    const float dop = d_opacity ? d_opacity[r] : 0.0f, ddp = d_depth ? d_depth[r] : 0.0f;
+    float total = 0.0f;
+    for (int64_t i = s0; i < s0 + cnt; ++i) total = total + sig[i] * (t1[i] - t0[i]);
+    float acc_after = total, suffix = 0.0f;
+    for (int64_t i = s0 + cnt - 1; i >= s0; --i) {
+        const float ts = t0[i], te = t1[i];
+        const float dt = te - ts;
+        const float sd = sig[i] * dt;
+        // optical depth before the sample; the first sample's is exactly 0 (no cancellation residue in T_0 = 1)
+        const float acc_before = (i == s0) ? 0.0f : (acc_after - sd);
+        const float T = __expf(-acc_before);
+        const float a = 1.0f - __expf(-sd);
+        const float w = T * a;
+        const float g = ((dc0 * rgbs[3 * i] + dc1 * rgbs[3 * i + 1]) + dc2 * rgbs[3 * i + 2]) + dop + ddp * ((ts + te) * 0.5f);
+        d_sig[i] = dt * (g * (T - w) - suffix);
+        d_rgbs[3 * i] = w * dc0;
+        d_rgbs[3 * i + 1] = w * dc1;
+        d_rgbs[3 * i + 2] = w * dc2;
+        suffix = suffix + g * w;
+        acc_after = acc_before;
+    }
+}
+
+}  // namespace ced
+
+extern "C" int ced_composite_backward(int64_t n_rays, const int64_t *packed_info, const float *t_starts, const float *t_ends,
+                                      const float *sigmas, const float *rgbs, const float *d_color, const float *d_opacity,
+                                      const float *d_depth, float *d_sigmas, float *d_rgbs, void *stream)
+{
+    CED_REQUIRE(n_rays >= 0, "composite_backward: n_rays < 0");
+    if (n_rays == 0) return CED_OK;
+    CED_REQUIRE(packed_info && t_starts && t_ends && sigmas && rgbs && d_color && d_sigmas && d_rgbs,
+                "composite_backward: null pointer");
+    hipLaunchKernelGGL(ced::composite_backward_kernel, dim3((unsigned)((n_rays + 255) / 256)), dim3(256), 0,
+                       (hipStream_t)stream, n_rays, packed_info, t_starts, t_ends, sigmas, rgbs, d_color, d_opacity, d_depth,
+                       d_sigmas, d_rgbs);
+    return ced::check_launch("composite_backward");
+}
+
+namespace ced {
 }  // namespace ced
 
 extern "C" int ced_render_weights(int64_t n_rays, const int64_t *packed_info, const float *t_starts,

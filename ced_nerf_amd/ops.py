@@ -248,6 +248,26 @@ def visibility_mask(packed_info, t_starts, t_ends, sigmas, early_stop_eps, alpha
     return mask
 
 
+def composite_backward(packed_info, t_starts, t_ends, sigmas, rgbs, d_color, d_opacity=None, d_depth=None):
+    """ced_composite_backward: (d_sigmas [S], d_rgbs [S,3]) of the un-normalised colors / opacities / depths."""
+    _chk(packed_info, torch.int64, "packed_info"); _chk(sigmas, torch.float32, "sigmas"); _chk(rgbs, torch.float32, "rgbs")
+    _chk(t_starts, torch.float32, "t_starts"); _chk(t_ends, torch.float32, "t_ends"); _chk(d_color, torch.float32, "d_color")
+    n_rays, S = packed_info.shape[0], sigmas.shape[0]
+    assert rgbs.shape == (S, 3) and d_color.shape == (n_rays, 3)
+    d_sig = torch.zeros((S,), device=sigmas.device, dtype=torch.float32)
+    d_rgb = torch.zeros((S, 3), device=sigmas.device, dtype=torch.float32)
+    if S == 0 or n_rays == 0:
+        return d_sig, d_rgb
+    for t, nm in ((d_opacity, "d_opacity"), (d_depth, "d_depth")):
+        if t is not None:
+            _chk(t, torch.float32, nm)
+            assert t.numel() == n_rays
+    rc = _lib.lib().ced_composite_backward(n_rays, _p(packed_info), _p(t_starts), _p(t_ends), _p(sigmas), _p(rgbs),
+                                           _p(d_color), _p(d_opacity), _p(d_depth), _p(d_sig), _p(d_rgb), _stream())
+    _lib.check(rc, "composite_backward")
+    return d_sig, d_rgb
+
+
 def composite_prefix_(packed_info, t_starts, t_ends, sigmas, rgbs, rgb, opacity, depth):
     _chk(packed_info, torch.int64, "packed_info"); _chk(rgbs, torch.float32, "rgbs")
     for nm, t in (("rgb", rgb), ("opacity", opacity), ("depth", depth)):

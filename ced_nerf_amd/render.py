@@ -65,3 +65,43 @@ def rendering(t_starts: Tensor, t_ends: Tensor, ray_indices: Tensor, n_rays: int
     dp_flat = depths.reshape(-1)
     ops.finalize_pixels_(bk, colors, op_flat, dp_flat)
     return colors, opacities, depths, extras
+
+
+class _CompositeFunction(torch.autograd.Function):
+    """(sigmas [S], rgbs [S,3]) -> un-normalised (colors [n,3], opacities [n,1], depths [n,1]) with the HIP forward
+    (render_weight_from_density + accumulate_along_rays) and the HIP backward ced_composite_backward."""
+
+    @staticmethod
+    def forward(ctx, sigmas, rgbs, t_starts, t_ends, packed):
+        sig = sigmas.detach().float().contiguous(); rgb = rgbs.detach().float().contiguous()
+        weights, _, _ = render_weight_from_density(t_starts, t_ends, sig, packed_info=packed)
+        colors = accumulate_along_rays(weights, values=rgb, packed_info=packed)
+        opacities = accumulate_along_rays(weights, values=None, packed_info=packed)
+        depths = accumulate_along_rays(weights, values=(t_starts + t_ends)[..., None] / 2.0, packed_info=packed)
+        ctx.save_for_backward(sig, rgb, t_starts, t_ends, packed)
+        return colors, opacities, depths
+
+    @staticmethod
+    def backward(ctx, d_colors, d_opacities, d_depths):
+        sig, rgb, t_starts, t_ends, packed = ctx.saved_tensors
+        d_sig, d_rgb = ops.composite_backward(packed, t_starts, t_ends, sig, rgb, d_colors.float().contiguous(),
+                                              d_opacities.float().reshape(-1).contiguous(),
+                                              d_depths.float().reshape(-1).contiguous())
+        return d_sig, d_rgb, None, None, None
+
+
+def rendering_train(t_starts: Tensor, t_ends: Tensor, ray_indices: Tensor, n_rays: int, rgb_sigma_fn: Callable,
+                    render_bkgd: Optional[Tensor] = None):
+    """cednerf/render.py:58-176 with gradients (the training call, train_real.py:339-350): `rgb_sigma_fn` returns
+    differentiable (rgbs, sigmas); compositing runs on the HIP kernels in both directions.  First pieces of the
+    training path: returns (colors, opacities, depths, extras) like `rendering`."""
+    rgbs, sigma_results = rgb_sigma_fn(t_starts, t_ends, ray_indices)
+    sigmas = sigma_results["density"].squeeze(-1) if isinstance(sigma_results, dict) else sigma_results
+    assert rgbs.shape[-1] == 3, "rgbs must have 3 channels, got {}".format(rgbs.shape)
+    assert sigmas.shape == t_starts.shape, "sigmas must have shape of (N, 1)! Got {}".format(sigmas.shape)
+    packed = _packed_info_from(ray_indices, n_rays)
+    colors, opacities, depths = _CompositeFunction.apply(sigmas, rgbs, t_starts.contiguous(), t_ends.contiguous(), packed)
+    depths = depths / opacities.clamp_min(torch.finfo(torch.float32).eps)
+    if render_bkgd is not None:
+        colors = colors + render_bkgd.to(colors.device, torch.float32) * (1.0 - opacities)
+    return colors, opacities, depths, {"sigmas": sigmas, "rgbs": rgbs}

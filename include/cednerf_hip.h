@@ -207,6 +207,16 @@ int ced_composite_prefix(int64_t n_rays, const int64_t *packed_info, const float
                          const float *t_ends, const float *sigmas, const float *rgbs,
                          float *rgb, float *opacity, float *depth, void *stream);
 
+/* Backward of the training-time compositing: the derivative of the un-normalised
+ * (colors, opacities, depths) = accumulate_along_rays(render_weight_from_density(...), {rgbs, 1, t_mid}) of
+ * cednerf/render.py:158-169 w.r.t. the per-sample sigmas [S] and rgbs [S,3], given d_color [n_rays,3],
+ * d_opacity [n_rays] and d_depth [n_rays] (the last two may be NULL = zero).  Replaces the backward of nerfacc's
+ * render_weight_from_density / accumulate_along_rays autograd functions. */
+int ced_composite_backward(int64_t n_rays, const int64_t *packed_info, const float *t_starts,
+                           const float *t_ends, const float *sigmas, const float *rgbs,
+                           const float *d_color, const float *d_opacity, const float *d_depth,
+                           float *d_sigmas, float *d_rgbs, void *stream);
+
 /* ced_composite_prefix plus the per-iteration bookkeeping of cednerf/utils.py:301-307 in the same
  * launch: ray_mask[r] = opacity[r] <= opc_thres && count[r] == n_samples_iter, and
  * stats[0] += number of rays still alive, stats[1] += samples composited (device int64[2], the

@@ -732,6 +732,39 @@ void ced_o_accumulate(int64_t n_rays, const int64_t *packed_info, const float *w
     }
 }
 
+/* Backward of the training-time compositing (next row f2): the chain render_weight_from_density ->
+ * accumulate_along_rays x3 of cednerf/render.py:158-169 (colors, opacities, depths), differentiated w.r.t. the
+ * per-sample sigmas and rgbs.  Evaluated in DOUBLE (the derivative of the real-valued formula):
+ *   w_i = T_i a_i,  T_i = exp(-sum_{j<i} sd_j),  a_i = 1 - exp(-sd_i),  sd_i = sigma_i (t1_i - t0_i)
+ *   g_i = dL/dw_i = <d_color, rgb_i> + d_opacity + d_depth * (t0_i + t1_i)/2
+ *   dL/drgb_i = w_i d_color;   dL/dsigma_i = (t1_i - t0_i) [ g_i (T_i - w_i) - sum_{k>i} g_k w_k ]. */
+void ced_o_composite_backward(int64_t n_rays, const int64_t *packed_info, const float *t_starts, const float *t_ends,
+                              const float *sigmas, const float *rgbs, const float *d_color /* [n_rays,3] */,
+                              const float *d_opacity /* [n_rays] */, const float *d_depth /* [n_rays] */,
+                              double *d_sigmas, double *d_rgbs /* [S,3] */)
+{
+#pragma omp parallel for schedule(dynamic, 256)
+    for (int64_t r = 0; r < n_rays; ++r) {
+        int64_t s0 = packed_info[2 * r], cnt = packed_info[2 * r + 1];
+        double total = 0.0;
+        for (int64_t i = s0; i < s0 + cnt; ++i) total += (double)sigmas[i] * ((double)t_ends[i] - (double)t_starts[i]);
+        double acc_after = total, suffix = 0.0;                      /* sum_{j<=i} sd_j, sum_{k>i} g_k w_k */
+        for (int64_t i = s0 + cnt - 1; i >= s0; --i) {
+            double dt = (double)t_ends[i] - (double)t_starts[i];
+            double sd = (double)sigmas[i] * dt;
+            double acc_before = acc_after - sd;
+            double T = exp(-acc_before), a = 1.0 - exp(-sd), w = T * a;
+            double g = (double)d_color[3 * r] * rgbs[3 * i] + (double)d_color[3 * r + 1] * rgbs[3 * i + 1] +
+                       (double)d_color[3 * r + 2] * rgbs[3 * i + 2] + (double)d_opacity[r] +
+                       (double)d_depth[r] * (((double)t_starts[i] + (double)t_ends[i]) / 2.0);
+            d_sigmas[i] = dt * (g * (T - w) - suffix);
+            for (int c = 0; c < 3; ++c) d_rgbs[3 * i + c] = w * (double)d_color[3 * r + c];
+            suffix += g * w;
+            acc_after = acc_before;
+        }
+    }
+}
+
 /* render_visibility_from_density (inside OccGridEstimator.sampling, utils.py:115-125). */
 void ced_o_visibility(int64_t n_rays, const int64_t *packed_info, const float *t_starts,
                       const float *t_ends, const float *sigmas, float early_stop_eps, float alpha_thre,

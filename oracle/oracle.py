@@ -322,6 +322,17 @@ def accumulate_along_rays_(weights, values, packed_info, outputs):
     return outputs
 
 
+def composite_backward(packed_info, t_starts, t_ends, sigmas, rgbs, d_color, d_opacity, d_depth):
+    """Derivative of (colors, opacities, depths) of cednerf/render.py:158-169 w.r.t. (sigmas, rgbs), in float64."""
+    n_rays = packed_info.shape[0]
+    S = sigmas.shape[0]
+    ds = np.zeros((S,), np.float64); dc = np.zeros((S, 3), np.float64)
+    lib().ced_o_composite_backward(C.c_int64(n_rays), _p(np.ascontiguousarray(packed_info, dtype=np.int64)), _p(_f32(t_starts)),
+                                   _p(_f32(t_ends)), _p(_f32(sigmas)), _p(_f32(rgbs)), _p(_f32(d_color)),
+                                   _p(_f32(d_opacity).reshape(-1)), _p(_f32(d_depth).reshape(-1)), _p(ds), _p(dc))
+    return ds, dc
+
+
 def visibility_mask(t_starts, t_ends, sigmas, packed_info, early_stop_eps, alpha_thre):
     s = t_starts.shape[0]
     mask = np.empty((s,), np.uint8)
