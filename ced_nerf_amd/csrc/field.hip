@@ -449,7 +449,7 @@ struct HashBwdArgs {
     int64_t n;
     const float *x, *dy;
     float *grad_table, *dx;
-    int n_levels, table_dtype;
+    int n_levels, table_dtype, dx_scaled;
     const void *table;
     float scale[CED_MAX_LEVELS];
     uint32_t res[CED_MAX_LEVELS], offset[CED_MAX_LEVELS], size[CED_MAX_LEVELS], hashed[CED_MAX_LEVELS];
@@ -507,7 +507,7 @@ __global__ __launch_bounds__(256) void hash_backward_kernel(HashBwdArgs A)
                         f0 = half_bits_to_float((uint16_t)(u & 0xffffu)); f1 = half_bits_to_float((uint16_t)(u >> 16));
                     }
                     // d w / d pos_a = +-(product of the other two factors)
-                    const float dot = f0 * g0 + f1 * g1;
+                    const float dot = (f0 * g0 + f1 * g1) * (A.dx_scaled ? sc : 1.0f);
                     gx[0] += dot * ((c & 1) ? (wy * wz) : -(wy * wz));
                     gx[1] += dot * ((c & 2) ? (wx * wz) : -(wx * wz));
                     gx[2] += dot * ((c & 4) ? (wx * wy) : -(wx * wy));
@@ -813,7 +813,7 @@ extern "C" int ced_hash_encode(const ced_hash_desc *desc, int64_t n, const float
 }
 
 extern "C" int ced_hash_encode_backward(const ced_hash_desc *desc, int64_t n, const float *x, const float *dy,
-                                        float *grad_table, float *dx, void *stream)
+                                        float *grad_table, float *dx, int32_t dx_scaled, void *stream)
 {
     int rc = ced::validate_hash(desc, "hash_encode_backward");
     if (rc) return rc;
@@ -825,6 +825,7 @@ extern "C" int ced_hash_encode_backward(const ced_hash_desc *desc, int64_t n, co
     ced::HashBwdArgs A{};
     A.n = n; A.x = x; A.dy = dy; A.grad_table = grad_table; A.dx = dx;
     A.n_levels = desc->n_levels; A.table_dtype = desc->table_dtype; A.table = desc->table;
+    A.dx_scaled = dx_scaled ? 1 : 0;
     for (int l = 0; l < CED_MAX_LEVELS; ++l) {
         A.scale[l] = desc->scale[l]; A.res[l] = desc->res[l]; A.offset[l] = desc->offset[l];
         A.size[l] = desc->size[l]; A.hashed[l] = desc->hashed[l];

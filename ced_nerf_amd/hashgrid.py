@@ -57,8 +57,11 @@ class HashEncoder(torch.nn.Module):
     First piece of the training path."""
 
     def __init__(self, max_params: float = 2 ** 19, levels: int = 16, base_res: float = 16.0, max_res: float = 2048.0,
-                 feature_per_level: int = 2, device="cuda"):
+                 feature_per_level: int = 2, device="cuda", true_position_gradient: bool = False):
         super().__init__()
+        # False: dL/dx as the reference's kernel computes it (no per-level `scale` factor, :212-226); True: the
+        # gradient of the forward w.r.t. x (what a position-predicting network in front of the grid needs)
+        self.true_position_gradient = bool(true_position_gradient)
         if feature_per_level != 2:
             raise NotImplementedError("the HIP hash grid stores 2 features per entry")
         log2T = int(round(np.log2(max_params)))
@@ -99,5 +102,6 @@ class _HashEncodeFunction(torch.autograd.Function):
         from . import ops
         x, tab = ctx.saved_tensors
         grad_table, dx = ops.hash_encode_backward(ctx.module._desc(tab), x, dy.float().contiguous(),
-                                                  want_dx=ctx.needs_input_grad[0])
+                                                  want_dx=ctx.needs_input_grad[0],
+                                                  dx_scaled=ctx.module.true_position_gradient)
         return dx, grad_table, None

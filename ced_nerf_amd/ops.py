@@ -149,7 +149,7 @@ def hash_encode(desc: _lib.HashDesc, x: torch.Tensor, t: Optional[torch.Tensor] 
 
 
 def hash_encode_backward(desc: _lib.HashDesc, x: torch.Tensor, dy: torch.Tensor,
-                         grad_table: Optional[torch.Tensor] = None, want_dx: bool = True):
+                         grad_table: Optional[torch.Tensor] = None, want_dx: bool = True, dx_scaled: bool = False):
     """ced_hash_encode_backward: (grad_table [E,2] fp32 -- accumulated into when given, else fresh --, dx [n,3] or None)."""
     _chk(x, torch.float32, "x"); _chk(dy, torch.float32, "dy")
     n = x.shape[0]
@@ -160,7 +160,8 @@ def hash_encode_backward(desc: _lib.HashDesc, x: torch.Tensor, dy: torch.Tensor,
         _chk(grad_table, torch.float32, "grad_table")
         assert grad_table.shape == (int(desc.total_entries), 2)
     dx = torch.empty((n, 3), device=x.device, dtype=torch.float32) if want_dx else None
-    rc = _lib.lib().ced_hash_encode_backward(C.byref(desc), n, _p(x), _p(dy), _p(grad_table), _p(dx), _stream())
+    rc = _lib.lib().ced_hash_encode_backward(C.byref(desc), n, _p(x), _p(dy), _p(grad_table), _p(dx), int(dx_scaled),
+                                             _stream())
     _lib.check(rc, "hash_encode_backward")
     return grad_table, dx
 

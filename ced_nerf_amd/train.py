@@ -1,0 +1,149 @@
+"""Training-time field and step: first end-to-end slice of the training path.
+
+What runs where, for now:
+  * sampling (occupancy-grid marching, stratified)            -> HIP  (nerfacc_api.OccGridEstimator.sampling)
+  * hash-grid encode, forward and backward                    -> HIP  (ced_hash_encode / ced_hash_encode_backward)
+  * compositing, forward and backward                         -> HIP  (render.rendering_train)
+  * the three bias-free MLPs, forward and backward            -> plain library GEMMs through torch (rocBLAS); the
+    fused forward kernel of model.py is inference-only.  Encodings and the small element-wise pieces are torch too.
+`TrainableField` keeps the parameter names and layout of `DNGPradianceField` (hash_table, xyz_wrap, mlp_base,
+mlp_head as W[out][in]), so `to_inference()` hands the trained weights to the fused kernels unchanged, and
+`tests/test_gpu_parity.py` checks that the two forwards agree.  Mirrors cednerf/model.py:354-488 (forward) and the
+loss / optimiser lines of train_real.py:339-380 (smooth-L1 on colours, Adam).
+"""
+from __future__ import annotations
+
+import math
+from typing import Dict, Optional
+
+import numpy as np
+import torch
+
+from . import ops
+from .hashgrid import level_tables
+from .render import rendering_train
+
+
+class _HashFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, table, cfg):
+        tab = table.detach().contiguous()
+        desc, _ = ops.make_hash_desc(tab, cfg["base_res"], cfg["max_res"], cfg["n_levels"], cfg["log2_hashmap_size"], False)
+        out = ops.hash_encode(desc, x.detach().contiguous())
+        ctx.save_for_backward(x.detach().contiguous(), tab)
+        ctx.cfg = cfg
+        return out
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, tab = ctx.saved_tensors
+        cfg = ctx.cfg
+        desc, _ = ops.make_hash_desc(tab, cfg["base_res"], cfg["max_res"], cfg["n_levels"], cfg["log2_hashmap_size"], False)
+        grad_table, dx = ops.hash_encode_backward(desc, x, dy.float().contiguous(), want_dx=ctx.needs_input_grad[0],
+                                                  dx_scaled=True)
+        return dx, grad_table, None
+
+
+class TrainableField(torch.nn.Module):
+    """Differentiable DNGPradianceField (cednerf/model.py:97-488) with the inference module's parameters."""
+
+    def __init__(self, params: Dict, device="cuda"):
+        super().__init__()
+        h = params["hash"]
+        if h.get("temporal", False) or np.asarray(h["table"]).dtype != np.float32:
+            raise NotImplementedError("training uses the fp32, non-temporal hash table")
+        self.hash_cfg = dict(base_res=h["base_res"], max_res=h["max_res"], n_levels=h["n_levels"],
+                             log2_hashmap_size=h["log2_hashmap_size"])
+        assert level_tables(h["base_res"], h["max_res"], h["n_levels"], h["log2_hashmap_size"])["total"] == h["table"].shape[0]
+        T = lambda a: torch.nn.Parameter(torch.from_numpy(np.ascontiguousarray(a, dtype=np.float32)).to(device))
+        self.register_buffer("aabb", torch.from_numpy(np.asarray(params["aabb"], np.float32)).to(device))
+        self.moving_step = float(params["moving_step"])
+        self.use_div_offsets = bool(params["use_div_offsets"])
+        self.time_mode = int(params["time_mode"])
+        self.hash_table = T(h["table"])
+        self.xyz_wrap = torch.nn.ParameterList([T(w) for w in params["xyz_wrap"]])
+        self.mlp_base = torch.nn.ParameterList([T(w) for w in params["mlp_base"]])
+        self.mlp_head = torch.nn.ParameterList([T(w) for w in params["mlp_head"]])
+        if self.time_mode:
+            from .encoder import SinusoidalEncoder, SinusoidalEncoderWithExp
+            self.time_encoder = SinusoidalEncoder(1, 0, 4, True)
+            self.time_encoder_feat = SinusoidalEncoderWithExp(1, 0, 4, True)
+
+    @staticmethod
+    def _mlp(x, weights):
+        for w in weights[:-1]:
+            x = torch.relu(x @ w.t())
+        return x @ weights[-1].t()
+
+    def forward(self, positions: torch.Tensor, t: torch.Tensor, directions: torch.Tensor):
+        """positions [N,3] world, t [N,1] in [0,1], directions [N,3] -> (rgb [N,3], sigma [N])."""
+        x, tt = positions.float(), t.reshape(-1, 1).float()
+        # tcnn Frequency(4) on (x,y,z,t): [dim][freq][sin,cos] of pi * 2^k * v  
+        v = torch.cat([x, tt], dim=-1)                                             # [N,4]
+        ang = math.pi * v[:, :, None] * (2.0 ** torch.arange(4, device=x.device, dtype=torch.float32))   # [N,4,4]
+        enc = torch.stack([torch.sin(ang), torch.sin(ang + 0.5 * math.pi)], dim=-1).reshape(x.shape[0], 32)
+        mo = self._mlp(enc, list(self.xyz_wrap))
+        move = mo[:, :3] * self.moving_step                                         # model.py:356-363
+        if self.use_div_offsets:
+            move = move + torch.tanh(mo[:, 3:6]) * self.moving_step
+        xn = (x + move - self.aabb[:3]) / (self.aabb[3:] - self.aabb[:3])           # model.py:378-379
+        selector = ((xn > 0.0) & (xn < 1.0)).all(dim=-1)                            # model.py:383
+        feat = _HashFn.apply(xn.clamp(0.0, 1.0), self.hash_table, self.hash_cfg)
+        if self.time_mode:                                                          # model.py:386-403
+            mn = move.norm(dim=-1, keepdim=True)
+            te = self.time_encoder(tt) if self.time_mode == 1 else self.time_encoder_feat(tt, mn)
+            feat = torch.cat([feat, te], dim=-1)
+        bout = self._mlp(feat, list(self.mlp_base))
+        sigma = torch.exp(bout[:, 0] - 1.0) * selector.to(bout.dtype)               # trunc_exp(x - 1) * selector
+        d = directions.float()
+        u = (d / d.norm(dim=-1, keepdim=True) + 1.0) / 2.0
+        w = u * 2.0 - 1.0
+        sh = torch.stack([torch.full_like(w[:, 0], 0.28209479177387814), -0.48860251190291987 * w[:, 1],
+                          0.48860251190291987 * w[:, 2], -0.48860251190291987 * w[:, 0]], dim=-1)
+        rgb = torch.sigmoid(self._mlp(torch.cat([sh, bout[:, 1:]], dim=-1), list(self.mlp_head)))
+        return rgb, sigma
+
+    def export_params(self) -> Dict:
+        g = lambda p: p.detach().cpu().numpy()
+        return dict(aabb=g(self.aabb), moving_step=self.moving_step, use_div_offsets=self.use_div_offsets,
+                    time_mode=self.time_mode, hash=dict(table=g(self.hash_table), **self.hash_cfg),
+                    xyz_wrap=[g(p) for p in self.xyz_wrap], mlp_base=[g(p) for p in self.mlp_base],
+                    mlp_head=[g(p) for p in self.mlp_head])
+
+    def to_inference(self, device="cuda", mlp_precision: str = "f32"):
+        """The fused-kernel module with these weights."""
+        from .model import DNGPradianceField
+        return DNGPradianceField.from_params(self.export_params(), device, mlp_precision=mlp_precision).eval()
+
+
+def train_step(field: TrainableField, estimator, optimizer, rays_o: torch.Tensor, rays_d: torch.Tensor,
+               timestamps: torch.Tensor, target_rgb: torch.Tensor, render_step_size: float, near_plane: float = 0.0,
+               far_plane: float = 1e10, cone_angle: float = 0.0, alpha_thre: float = 0.0,
+               render_bkgd: Optional[torch.Tensor] = None) -> Dict:
+    """One optimisation step on a batch of rays (train_real.py:339-380): stratified occupancy-grid sampling with the
+    current density (no gradient), differentiable field + compositing, smooth-L1 colour loss, optimiser step."""
+    n_rays = rays_o.shape[0]
+    ts = timestamps.reshape(-1, 1).float()
+    if ts.shape[0] == 1:
+        ts = ts.expand(n_rays, 1)
+
+    def sigma_fn(t_starts, t_ends, ray_indices):
+        with torch.no_grad():
+            pos = rays_o[ray_indices] + rays_d[ray_indices] * ((t_starts + t_ends)[:, None] / 2.0)
+            return field(pos, ts[ray_indices], rays_d[ray_indices])[1]
+
+    ray_indices, t_starts, t_ends = estimator.sampling(rays_o, rays_d, sigma_fn=sigma_fn, near_plane=near_plane,
+                                                       far_plane=far_plane, render_step_size=render_step_size,
+                                                       stratified=True, cone_angle=cone_angle, alpha_thre=alpha_thre)
+
+    def rgb_sigma_fn(t_starts, t_ends, ray_indices):
+        pos = rays_o[ray_indices] + rays_d[ray_indices] * ((t_starts + t_ends)[:, None] / 2.0)
+        return field(pos, ts[ray_indices], rays_d[ray_indices])
+
+    colors, opacities, depths, _ = rendering_train(t_starts, t_ends, ray_indices, n_rays, rgb_sigma_fn,
+                                                    render_bkgd=render_bkgd)
+    loss = torch.nn.functional.smooth_l1_loss(colors, target_rgb)
+    optimizer.zero_grad(set_to_none=True)
+    loss.backward()
+    optimizer.step()
+    return {"loss": float(loss.detach()), "n_samples": int(t_starts.shape[0])}

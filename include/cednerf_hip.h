@@ -160,9 +160,10 @@ int ced_hash_encode(const ced_hash_desc *desc, int64_t n, const float *x, const 
  * hash_encoder_backward_kernel, taichi_kernel/hash_encoder_half.py:164-226.  dy [n, 2*n_levels] is the gradient
  * w.r.t. the encoder output; grad_table [total_entries, 2] fp32 is ACCUMULATED into (one hardware atomic add per
  * corner and feature; zero it first for a fresh gradient, as HashEncoder.backward does at :362-364); dx [n, 3]
- * (optional) receives the position gradient, w.r.t. the scaled position as in the reference (no `scale` factor). */
+ * (optional) receives the position gradient: dx_scaled = 0 as the reference computes it (per level w.r.t. the
+ * scaled position, i.e. without the `scale` factor), dx_scaled = 1 the gradient w.r.t. x itself. */
 int ced_hash_encode_backward(const ced_hash_desc *desc, int64_t n, const float *x, const float *dy,
-                             float *grad_table, float *dx, void *stream);
+                             float *grad_table, float *dx, int32_t dx_scaled, void *stream);
 
 /* DNGPradianceField.forward(positions, t, directions) -- cednerf/model.py:468-488 (query_move
  * :354-365, query_density :367-445, _query_rgb :447-466), fused into one kernel.

@@ -435,9 +435,9 @@ void ced_o_hash_encode(const ced_o_hash_t *h, int64_t n, const float *x, const f
  *                         reference adds with atomics in no particular order, so only the sum is specified)
  *   dx [n][3] (optional)  = sum over levels and corners of (table_feat . dy) * dw/dpos, with the reference's
  *                         form dw/dpos_d = w / (+-other factor) (:212-213) and, like the reference, WITHOUT
- *                         the d pos / d x = scale factor. */
+ *                         the d pos / d x = scale factor unless dx_scaled (the true gradient w.r.t. x). */
 void ced_o_hash_encode_backward(const ced_o_hash_t *h, int64_t n, const float *x_in, const float *dy,
-                                double *grad_table, float *dx)
+                                double *grad_table, float *dx, int dx_scaled /* 1: times d pos / d x = scale */)
 {
     for (int64_t i = 0; i < n; ++i) {
         float x[3];
@@ -473,7 +473,7 @@ void ced_o_hash_encode_backward(const ced_o_hash_t *h, int64_t n, const float *x
                     f0 = half_to_float(tb[0]); f1 = half_to_float(tb[1]);
                 }
                 const float dot = f0 * g0 + f1 * g1;
-                if (dx) for (int a = 0; a < 3; ++a) gx[a] = gx[a] + dot * (w / dwd[a]);
+                if (dx) for (int a = 0; a < 3; ++a) gx[a] = gx[a] + (dx_scaled ? sc : 1.0f) * (dot * (w / dwd[a]));
                 grad_table[(size_t)idx * 2] += (double)(w * g0);
                 grad_table[(size_t)idx * 2 + 1] += (double)(w * g1);
             }

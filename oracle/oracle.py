@@ -174,13 +174,14 @@ class OracleField:
         lib().ced_o_hash_encode(C.byref(self.hash_t), C.c_int64(n), _p(x), _p(tt), _p(out))
         return out
 
-    def hash_encode_backward(self, x: np.ndarray, dy: np.ndarray, want_dx: bool = True):
+    def hash_encode_backward(self, x: np.ndarray, dy: np.ndarray, want_dx: bool = True, dx_scaled: bool = False):
         """hash_encoder_backward_kernel (hash_encoder_half.py:164-226): (grad_table [E,2] float64, dx [n,3])."""
         x = _f32(x); dy = _f32(dy).reshape(x.shape[0], -1)
         n = x.shape[0]
         grad = np.zeros((self.levels["total"], 2), np.float64)
         dx = np.empty((n, 3), np.float32) if want_dx else None
-        lib().ced_o_hash_encode_backward(C.byref(self.hash_t), C.c_int64(n), _p(x), _p(dy), _p(grad), _p(dx))
+        lib().ced_o_hash_encode_backward(C.byref(self.hash_t), C.c_int64(n), _p(x), _p(dy), _p(grad), _p(dx),
+                                         C.c_int(int(dx_scaled)))
         return grad, dx
 
     def hash_indices(self, x: np.ndarray) -> np.ndarray:

@@ -314,3 +314,5 @@ def test_oracle_hash_backward_is_the_adjoint_of_the_forward(oracle):
             fd = ((of.hash_encode(xp).astype(np.float64) - of.hash_encode(xm).astype(np.float64)) * dyl).sum(axis=1) / (2 * eps * sc)
             err = np.abs(fd[ok] - dxl[ok, a]).max() / max(np.abs(dxl[ok, a]).max(), 1e-6)
             assert err < 2e-2, (l, a, err)
+        _, dxs = of.hash_encode_backward(x, dyl, dx_scaled=True)          # times d pos / d x = scale
+        assert np.allclose(dxs, dxl * np.float32(sc), rtol=1e-4, atol=1e-6 * float(np.abs(dxs).max()))
