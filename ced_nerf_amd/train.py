@@ -4,8 +4,9 @@ What runs where, for now:
   * sampling (occupancy-grid marching, stratified)            -> HIP  (nerfacc_api.OccGridEstimator.sampling)
   * hash-grid encode, forward and backward                    -> HIP  (ced_hash_encode / ced_hash_encode_backward)
   * compositing, forward and backward                         -> HIP  (render.rendering_train)
+  * gradient-free densities of the sampling pass               -> HIP  (the fused inference kernel on the shared parameters)
   * the three bias-free MLPs, forward and backward            -> plain library GEMMs through torch (rocBLAS); the
-    fused forward kernel of model.py is inference-only.  Encodings and the small element-wise pieces are torch too.
+    fused forward kernel of model.py has no backward yet.  Encodings and the small element-wise pieces are torch too.
 `TrainableField` keeps the parameter names and layout of `DNGPradianceField` (hash_table, xyz_wrap, mlp_base,
 mlp_head as W[out][in]), so `to_inference()` hands the trained weights to the fused kernels unchanged, and
 `tests/test_gpu_parity.py` checks that the two forwards agree.  Mirrors cednerf/model.py:354-488 (forward) and the
@@ -111,9 +112,26 @@ class TrainableField(torch.nn.Module):
                     mlp_head=[g(p) for p in self.mlp_head])
 
     def to_inference(self, device="cuda", mlp_precision: str = "f32"):
-        """The fused-kernel module with these weights."""
+        """The fused-kernel module with (a copy of) these weights."""
         from .model import DNGPradianceField
         return DNGPradianceField.from_params(self.export_params(), device, mlp_precision=mlp_precision).eval()
+
+    def shared_inference(self):
+        """A fused-kernel module on the SAME parameter tensors (no copy): its weight blob is re-packed whenever an
+        optimiser step has changed them (the descriptor is keyed on the tensors' versions).  Used for the
+        gradient-free density queries of the sampling pass and of the occupancy-grid refresh."""
+        if getattr(self, "_shared", None) is None:
+            from .model import DNGPradianceField
+            h = self.hash_cfg
+            m = DNGPradianceField(aabb=self.aabb, dst_resolution=h["max_res"], base_resolution=h["base_res"],
+                                  n_levels=h["n_levels"], log2_hashmap_size=h["log2_hashmap_size"],
+                                  moving_step=self.moving_step, use_div_offsets=self.use_div_offsets,
+                                  use_time_embedding=self.time_mode != 0, use_time_attenuation=self.time_mode == 2)
+            m.hash_table = self.hash_table
+            m.xyz_wrap, m.mlp_base, m.mlp_head = self.xyz_wrap, self.mlp_base, self.mlp_head
+            m.aabb = self.aabb
+            object.__setattr__(self, "_shared", m.eval())          # not a sub-module: the parameters are ours
+        return self._shared
 
 
 def train_step(field: TrainableField, estimator, optimizer, rays_o: torch.Tensor, rays_d: torch.Tensor,
@@ -127,10 +145,13 @@ def train_step(field: TrainableField, estimator, optimizer, rays_o: torch.Tensor
     if ts.shape[0] == 1:
         ts = ts.expand(n_rays, 1)
 
+    fused = field.shared_inference()
+
     def sigma_fn(t_starts, t_ends, ray_indices):
-        with torch.no_grad():
-            pos = rays_o[ray_indices] + rays_d[ray_indices] * ((t_starts + t_ends)[:, None] / 2.0)
-            return field(pos, ts[ray_indices], rays_d[ray_indices])[1]
+        # gradient-free density of every marched sample: the fused inference kernel on the current weights
+        fused.train()                                     # per-ray timestamps, as in training (utils.py:86-104)
+        _, sigma = fused.query_rays(rays_o, rays_d, ray_indices, t_starts, t_ends, ts, want_rgb=False)
+        return sigma
 
     ray_indices, t_starts, t_ends = estimator.sampling(rays_o, rays_d, sigma_fn=sigma_fn, near_plane=near_plane,
                                                        far_plane=far_plane, render_step_size=render_step_size,
