@@ -10,7 +10,8 @@ What runs where, for now:
 `TrainableField` keeps the parameter names and layout of `DNGPradianceField` (hash_table, xyz_wrap, mlp_base,
 mlp_head as W[out][in]), so `to_inference()` hands the trained weights to the fused kernels unchanged, and
 `tests/test_gpu_parity.py` checks that the two forwards agree.  Mirrors cednerf/model.py:354-488 (forward) and the
-loss / optimiser lines of train_real.py:339-380 (smooth-L1 on colours, Adam).
+loss / optimiser lines of train_real.py:324-420 (occupancy refresh, smooth-L1 on colours, Adam, GradScaler, dynamic
+ray batch).
 """
 from __future__ import annotations
 
@@ -134,10 +135,29 @@ class TrainableField(torch.nn.Module):
         return self._shared
 
 
+def next_num_rays(num_rays: int, n_rendering_samples: int, target_sample_batch_size: int) -> int:
+    """Dynamic ray batch of train_real.py:354-360: keep the number of rendered samples per step near the target."""
+    if target_sample_batch_size <= 0 or n_rendering_samples <= 0:
+        return num_rays
+    return int(num_rays * (target_sample_batch_size / float(n_rendering_samples)))
+
+
+def refresh_occupancy(field: TrainableField, estimator, step: int, timestamps: torch.Tensor, render_step_size: float,
+                      occ_thre: float = 1e-2) -> None:
+    """train_real.py:324-336: the occupancy grid's EMA update, every n steps, with the current density evaluated by
+    the fused inference kernel on the shared parameters."""
+    from .model import make_occ_eval_fn
+    was_training = estimator.training
+    estimator.train()
+    estimator.update_every_n_steps(step=step, occ_eval_fn=make_occ_eval_fn(field.shared_inference(), timestamps, render_step_size),
+                                   occ_thre=occ_thre)
+    estimator.train(was_training)
+
+
 def train_step(field: TrainableField, estimator, optimizer, rays_o: torch.Tensor, rays_d: torch.Tensor,
                timestamps: torch.Tensor, target_rgb: torch.Tensor, render_step_size: float, near_plane: float = 0.0,
                far_plane: float = 1e10, cone_angle: float = 0.0, alpha_thre: float = 0.0,
-               render_bkgd: Optional[torch.Tensor] = None) -> Dict:
+               render_bkgd: Optional[torch.Tensor] = None, grad_scaler=None) -> Dict:
     """One optimisation step on a batch of rays (train_real.py:339-380): stratified occupancy-grid sampling with the
     current density (no gradient), differentiable field + compositing, smooth-L1 colour loss, optimiser step."""
     n_rays = rays_o.shape[0]
@@ -165,6 +185,11 @@ def train_step(field: TrainableField, estimator, optimizer, rays_o: torch.Tensor
                                                     render_bkgd=render_bkgd)
     loss = torch.nn.functional.smooth_l1_loss(colors, target_rgb)
     optimizer.zero_grad(set_to_none=True)
-    loss.backward()
-    optimizer.step()
+    if grad_scaler is not None:                            # train_real.py:252,414-419 (GradScaler(2**10))
+        grad_scaler.scale(loss).backward()
+        grad_scaler.step(optimizer)
+        grad_scaler.update()
+    else:
+        loss.backward()
+        optimizer.step()
     return {"loss": float(loss.detach()), "n_samples": int(t_starts.shape[0])}

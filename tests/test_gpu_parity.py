@@ -1007,3 +1007,16 @@ def test_training_steps_reduce_the_loss(oracle):
     first, last = np.mean(losses[:5]), np.mean(losses[-5:])
     print("training losses", [round(x, 5) for x in losses[::5]])
     assert last < 0.6 * first, (first, last)
+    # the other loop pieces of train_real.py:324-420: GradScaler, dynamic ray batch, occupancy refresh on the current density
+    from ced_nerf_amd.train import next_num_rays, refresh_occupancy
+    scaler = torch.amp.GradScaler("cuda", init_scale=2.0 ** 10)
+    idx = idx_all[:1024]
+    out = train_step(student, est, opt, o[idx].contiguous(), d[idx].contiguous(), ts, target[idx].contiguous(),
+                     cfg["render_step_size"], near_plane=cfg["near_plane"], far_plane=cfg["far_plane"], render_bkgd=bk,
+                     grad_scaler=scaler)
+    assert np.isfinite(out["loss"]) and next_num_rays(1024, out["n_samples"], 1 << 16) == int(1024 * (65536 / out["n_samples"]))
+    est2 = OccGridEstimator(cfg["aabb"], cfg["grid_resolution"], cfg["grid_levels"]).to(DEV)
+    for step in range(0, 64, 16):
+        refresh_occupancy(student, est2, step, ts, cfg["render_step_size"])
+    frac = est2.binaries.float().mean().item()
+    assert 0.0 < frac < 1.0, frac          # the synthetic field is dense almost everywhere; the refresh marks cells
