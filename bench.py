@@ -167,7 +167,8 @@ def main():
         r.tracer = tracers[-1][0]
         lane_renderers.append(r)
     # multi-rank: the pixel all-gather of one step overlaps the next step's kernels (own stream, no read-back)
-    renderer = cdist.PipelinedRenderer(lane_renderers, async_gather=world > 1)
+    renderer = cdist.PipelinedRenderer(lane_renderers, async_gather=world > 1,
+                                       field_max_blocks=int(os.environ.get("CED_FIELD_MAX_BLOCKS", "128")))
     field_ms, field_launches, field_samples = [0.0], [0], [0]
     step_no = [0]
 
@@ -254,7 +255,8 @@ def main():
             dist.destroy_process_group()
         return
     n_rays_step = n_frames * args.width * args.height
-    # latency of ONE frame rendered alone (no other frame in flight), for reference
+    # latency of ONE frame rendered alone (no other frame in flight), for reference (field launches on all CUs again)
+    renderer.restore_field_blocks()
     torch.cuda.synchronize()
     t1 = time.perf_counter()
     single_field = {"ms": 0.0, "launches": 0, "units": 0.0}

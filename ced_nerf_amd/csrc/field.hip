@@ -554,6 +554,7 @@ __global__ __launch_bounds__(256) void hash_backward_kernel(HashBwdArgs A)
 }
 
 int g_field_stagger = 0;          // field kernel: start-up phase offset between the waves of a SIMD, in s_sleep(127) units
+int g_field_max_blocks = 256;
 int g_field_spread_tiles = 1;     // field kernels: deal tiles across all CUs first (ced_set_option)
 bool g_march_early_out = true;    // frame renderer: conservative brick-level early-out (ced_set_option)
 
@@ -630,7 +631,7 @@ int launch_field(const ced_field_desc *d, FieldArgs &A, void *stream)
         const int64_t n_tiles = (A.n + 16 * nt - 1) / (16 * nt);
         const int waves = threads / 64;
         int64_t blocks = A.spread_tiles ? (n_tiles + 3) / 4 : (n_tiles + waves - 1) / waves;
-        if (blocks > 256) blocks = 256;     // one resident workgroup per CU, persistent over tiles
+        if (blocks > g_field_max_blocks) blocks = g_field_max_blocks;     // one resident workgroup per CU, persistent over tiles
         hipLaunchKernelGGL(kernel, dim3((unsigned)blocks), dim3(threads), 0, (hipStream_t)stream, A);
     };
     const int sel = (d->time_mode ? 1 : 0) | (A.table_dtype ? 2 : 0) | (A.temporal ? 4 : 0);
@@ -663,6 +664,11 @@ extern "C" int ced_set_option(const char *key, int value)
     if (strcmp(key, "field_stagger") == 0) {
         CED_REQUIRE(value >= 0 && value <= 64, "set_option: field_stagger must be 0..64");
         ced::g_field_stagger = value;
+        return CED_OK;
+    }
+    if (strcmp(key, "field_max_blocks") == 0) {
+        CED_REQUIRE(value >= 1 && value <= 256, "set_option: field_max_blocks must be 1..256");
+        ced::g_field_max_blocks = value;
         return CED_OK;
     }
     if (strcmp(key, "field_spread_tiles") == 0) {

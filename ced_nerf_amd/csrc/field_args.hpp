@@ -31,6 +31,7 @@ struct FieldArgs {
 
 extern bool g_march_early_out;
 extern int g_field_spread_tiles;
+extern int g_field_max_blocks;       // workgroups per field launch (<= CUs); fewer leaves CUs to other frames' kernels
 
 // Fills the field/hash parts of A from the descriptor, validates, and launches on `stream`.
 int launch_field(const ced_field_desc *d, FieldArgs &A, void *stream);

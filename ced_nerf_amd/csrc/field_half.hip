@@ -320,7 +320,7 @@ int launch_field_half(FieldArgs &A, int time_mode, int precision, void *stream)
         const int64_t n_tiles = (A.n + 16 * nt - 1) / (16 * nt);
         const int waves = threads / 64;
         int64_t blocks = A.spread_tiles ? (n_tiles + 3) / 4 : (n_tiles + waves - 1) / waves;
-        if (blocks > 256) blocks = 256;     // one resident workgroup per CU, persistent over tiles
+        if (blocks > g_field_max_blocks) blocks = g_field_max_blocks;     // one resident workgroup per CU, persistent over tiles
         hipLaunchKernelGGL(kernel, dim3((unsigned)blocks), dim3(threads), 0, (hipStream_t)stream, A);
     };
     const int sel = (time_mode ? 1 : 0) | (A.table_dtype ? 2 : 0) | (A.temporal ? 4 : 0);

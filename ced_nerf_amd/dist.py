@@ -159,9 +159,18 @@ class PipelinedRenderer:
     the marching / field kernels of the next; the returned images are valid after `wait_gathers()` (or a
     device synchronise), and the all-rank sample count stays on the device (`total_samples_tensor`)."""
 
-    def __init__(self, lanes, share_field_stream: bool = False, async_gather: bool = False):
+    def __init__(self, lanes, share_field_stream: bool = False, async_gather: bool = False,
+                 field_max_blocks: Optional[int] = 128):
         from concurrent.futures import ThreadPoolExecutor
         self.lanes = list(lanes)
+        # With several frames in flight a field launch is capped at half the CUs (process-wide library option): two
+        # frames' field kernels then run side by side and the third frame's marching / compositing launches find
+        # free CUs instead of queueing behind a chip-wide kernel (+5 % frames/s with 3 lanes; a frame alone is
+        # faster with all 256, which `restore_field_blocks()` puts back).
+        self.field_max_blocks = field_max_blocks if len(self.lanes) > 1 else None
+        if self.field_max_blocks is not None and torch.cuda.is_available() and str(self.lanes[0].device) != "cpu":
+            from . import _lib
+            _lib.check(_lib.lib().ced_set_option(b"field_max_blocks", int(self.field_max_blocks)))
         self.async_gather = bool(async_gather)
         self.comm_stream = None
         self.streams = [torch.cuda.Stream(device=l.device) if torch.cuda.is_available() and str(l.device) != "cpu"
@@ -208,6 +217,11 @@ class PipelinedRenderer:
                     t.record_stream(self.comm_stream)       # produced on the lane's stream, consumed here
                 outs.append(lane.gather(loc, sync_total=False))
         return outs
+
+    @staticmethod
+    def restore_field_blocks() -> None:
+        from . import _lib
+        _lib.check(_lib.lib().ced_set_option(b"field_max_blocks", 256))
 
     def wait_gathers(self) -> None:
         """Make the caller's stream wait for every gather issued so far (async_gather mode)."""

@@ -77,6 +77,8 @@ const char *ced_last_error_string(void);
  * "half_variant": the same for the half-precision kernels, 0 = 2 x 768 (default), 1 = 2 x 512, 2 = 2 x 1024;
  * "field_spread_tiles": 1 (default) deals the sample tiles of a launch across all CUs in groups of four before
  * any CU takes more (shorter last round, lower frame latency), 0 = contiguous tiles per workgroup;
+ * "field_max_blocks": workgroups per field launch, 1..256 (default 256 = one per CU; frames in flight use 128 so
+ * that two frames' field kernels run side by side);
  * "field_stagger": start-up phase offset between the waves of a SIMD (0 = none, default);
  * "march_early_out": 1 (default) lets ced_render_image_test stop walking a ray once a dilated
  * brick mask proves nothing occupied lies ahead, 0 walks every cell.  Results are identical for every setting. */
