@@ -5,8 +5,8 @@
 // query_density :367-445, _query_rgb :447-466), i.e. five tiny-cuda-nn launches plus ~12 torch
 // glue kernels per call, and the sigma_fn / rgb_sigma_fn closures of cednerf/utils.py:74-104,181-195.
 //
-// Execution shape (CDNA4): one 512-thread workgroup per CU (2 waves per SIMD), persistent over
-// 64-sample wave tiles.  All nine weight matrices (~86 KB fp32, pre-swizzled by the host into
+// Execution shape (CDNA4): one 768-thread workgroup per CU (3 waves per SIMD; other launch geometries
+// behind ced_set_option("field_variant")), persistent over 32-sample wave tiles.  All nine weight matrices (~86 KB fp32, pre-swizzled by the host into
 // MFMA A-fragment order) are staged into LDS once per workgroup and read with conflict-free
 // ds_read_b128.  The GEMMs run on v_mfma_f32_16x16x4_f32 with D^T = W * X^T (neurons on the
 // accumulator rows, samples on lanes): exact fp32, an ascending-k fused-multiply-add chain,

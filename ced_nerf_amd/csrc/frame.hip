@@ -2,13 +2,16 @@
 //
 // Same algorithm and the same per-ray sample sets as the reference's host loop (image-global
 // schedule N_samples = clamp(N_rays // N_alive, min, 64), termination checked between iterations),
-// but an iteration is three launches instead of ~15 kernels + torch glue:
-//   march_alloc : one wave per 64 rays marches its alive rays ONCE, stages the (t_start, t_end)
-//                 pairs in LDS, reserves a contiguous output range with a wave prefix sum + one
-//                 atomic per wave, and writes the ray-packed samples (no count pass, no scan);
-//   field       : the fused field kernel of field.hip on those samples (count read from device memory);
-//   composite   : per-ray front-to-back compositing + ray-mask update + alive/sample counters.
-// The host reads (n_alive, n_samples) with one 16-byte copy per iteration -- the same single sync the
+// but an iteration is four launches instead of ~15 kernels + torch glue:
+//   march_alloc : one lane per ALIVE ray marches it ONCE, stages the (t_start, t_end) pairs in LDS; the
+//                 workgroup reserves one contiguous output range (wave prefix sums + a single returning
+//                 atomic) and writes the ray-packed samples (no count pass, no scan);
+//   field       : the fused field kernel (field.hip / field_half.hip) on those samples (count read from device memory);
+//   composite   : per-ray front-to-back compositing over the alive list; survivors are appended to the next
+//                 iteration's list, one range reservation per workgroup;
+//   publish     : one thread copies the iteration's two counters into mapped pinned host memory and raises a
+//                 sequence number.
+// The host spins on that sequence number -- one round trip per iteration, the same single sync the
 // reference pays at cednerf/utils.py:231.  Sample order in memory differs from nerfacc's (waves
 // reserve ranges in arrival order) but every ray's samples are contiguous and in order, so pixels,
 // sample counts and the schedule are bit-identical.
