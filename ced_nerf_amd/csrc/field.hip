@@ -650,6 +650,7 @@ int launch_field(const ced_field_desc *d, FieldArgs &A, void *stream)
     case 1: CED_FIELD_CASE(2, 512) break;
     case 2: CED_FIELD_CASE(2, 768) break;
     case 3: CED_FIELD_CASE(2, 1024) break;
+    case 4: CED_FIELD_CASE(1, 1024) break;
     default: CED_FIELD_CASE(4, 512) break;
     }
 #undef CED_FIELD_CASE
@@ -685,7 +686,7 @@ extern "C" int ced_set_option(const char *key, int value)
         return CED_OK;
     }
     if (strcmp(key, "field_variant") == 0) {
-        CED_REQUIRE(value >= 0 && value <= 3, "set_option: field_variant must be 0..3");
+        CED_REQUIRE(value >= 0 && value <= 4, "set_option: field_variant must be 0..4");
         ced::g_field_variant = value;
         return CED_OK;
     }

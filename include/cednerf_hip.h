@@ -73,7 +73,7 @@ int ced_version(void);
 const char *ced_last_error_string(void);
 
 /* Tuning knobs (process-wide).  "field_variant": launch geometry of the fused field kernel,
- * 0 = 4 column tiles x 512 threads, 1 = 2 x 512, 2 = 2 x 768 (default), 3 = 2 x 1024;
+ * 0 = 4 column tiles x 512 threads, 1 = 2 x 512, 2 = 2 x 768 (default), 3 = 2 x 1024, 4 = 1 x 1024;
  * "half_variant": the same for the half-precision kernels, 0 = 2 x 768 (default), 1 = 2 x 512, 2 = 2 x 1024;
  * "field_spread_tiles": 1 (default) deals the sample tiles of a launch across all CUs in groups of four before
  * any CU takes more (shorter last round, lower frame latency), 0 = contiguous tiles per workgroup;
