@@ -189,9 +189,16 @@ def main():
     ref_event.record()
     t0 = time.perf_counter()
     samples_local = 0
-    for _ in range(args.steps):
-        out = step()
-        samples_local += out["local_samples"]
+    if os.environ.get("CED_BENCH_JOIN_STEPS", "0") != "0":
+        for _ in range(args.steps):
+            out = step()
+            samples_local += out["local_samples"]
+    else:
+        # the K steps as a stream: lanes do not wait for each other between steps (PipelinedRenderer.render_steps)
+        def before_frame(l, s_):
+            lane_renderers[l].tracer = tracers[l][s_ % len(tracers[l])]
+        rows = renderer.render_steps(ts, args.steps, before_frame=before_frame)
+        samples_local = sum(o["local_samples"] for row in rows for o in row)
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
@@ -234,9 +241,8 @@ def main():
         torch.cuda.synchronize()
         k = max(1, min(args.steps, 6))
         t_a = time.perf_counter()
-        s_loc = 0
-        for _ in range(k):
-            s_loc += step()["local_samples"]
+        rows_o = renderer.render_steps(ts, k)
+        s_loc = sum(o["local_samples"] for row in rows_o for o in row)
         torch.cuda.synchronize()
         if world > 1:
             dist.barrier()

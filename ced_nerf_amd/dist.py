@@ -218,6 +218,55 @@ class PipelinedRenderer:
                 outs.append(lane.gather(loc, sync_total=False))
         return outs
 
+    @torch.no_grad()
+    def render_steps(self, timestamps: torch.Tensor, n_steps: int, before_frame: Optional[Callable] = None):
+        """`n_steps` consecutive steps (each step = one frame per lane, as `render`) WITHOUT joining the lanes between
+        steps: every lane renders its frame n_steps times back to back, so a lane that finishes early starts its next
+        frame instead of waiting for the slowest one (a video is a stream of frames).  Gathers are issued by the
+        calling thread in (step, lane) order -- the same order on every rank -- as the frames complete.
+        `before_frame(lane_index, step)` runs on the lane's thread before each frame (e.g. to swap tracers).
+        Returns a list (per step) of lists (per lane) of `gather` results."""
+        import queue
+        L = len(self.lanes)
+        main = torch.cuda.current_stream() if self.streams[0] is not None else None
+        if main is not None:
+            for s in self.streams:
+                s.wait_stream(main)
+        done = [[queue.Queue(maxsize=1) for _ in range(L)] for _ in range(n_steps)]
+
+        def work(i):
+            for step in range(n_steps):
+                if before_frame is not None:
+                    before_frame(i, step)
+                done[step][i].put(self._lane(i, timestamps))
+
+        if self.pool is None:
+            work(0)
+            threads = []
+        else:
+            threads = [self.pool.submit(work, i) for i in range(L)]
+        if self.async_gather and self.streams[0] is not None and self.comm_stream is None:
+            self.comm_stream = torch.cuda.Stream(device=self.lanes[0].device)
+        outs = []
+        for step in range(n_steps):
+            row = []
+            for i, lane in enumerate(self.lanes):
+                loc = done[step][i].get()
+                if self.async_gather and self.streams[0] is not None:
+                    with torch.cuda.stream(self.comm_stream):
+                        self.comm_stream.wait_stream(self.streams[i])
+                        for t in loc[:3]:
+                            t.record_stream(self.comm_stream)
+                        row.append(lane.gather(loc, sync_total=False))
+                else:
+                    if main is not None:
+                        main.wait_stream(self.streams[i])
+                    row.append(lane.gather(loc))
+            outs.append(row)
+        for t in threads:
+            t.result()
+        return outs
+
     @staticmethod
     def restore_field_blocks() -> None:
         from . import _lib

@@ -791,6 +791,12 @@ def test_pipelined_frames_equal_sequential_frames(oracle, full_frame):
             assert out["total_samples"] == want[3] and want[3] > 10000
             assert torch.equal(out["rgb"][0], want[0]) and torch.equal(out["opacity"][0], want[1])
             assert torch.equal(out["depth"][0], want[2])
+    # the same as a stream of steps (lanes do not wait for each other between steps)
+    for row in pipe.render_steps(ts, 4):
+        torch.cuda.synchronize()
+        for out, want in zip(row, singles):
+            assert out["total_samples"] == want[3]
+            assert torch.equal(out["rgb"][0], want[0]) and torch.equal(out["depth"][0], want[2])
     shared = PipelinedRenderer(lanes, share_field_stream=True)
     outs = shared.render(ts)
     torch.cuda.synchronize()
