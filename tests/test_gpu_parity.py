@@ -538,6 +538,52 @@ def test_render_image_test_parity(oracle, name, regime, wh):
     assert_bitexact(N(dp), w_dp, "depth (bit-exact)")
 
 
+@pytest.mark.parametrize("seed", range(int(__import__("os").environ.get("CED_FUZZ_SEEDS", "8"))))
+def test_render_image_test_random_configurations(oracle, seed):
+    """Fuzz over the knobs the three dataset configs do not vary together: grid resolution and level count, step size,
+    cone angle, near / far planes, alpha threshold, camera convention and distance (including a camera inside the
+    box), irregular occupancy, model flags.  The native frame loop against the oracle: schedule, counts, pixels."""
+    from ced_nerf_amd import ops, synthetic as S
+    from ced_nerf_amd.utils import render_image_test
+    rng = np.random.default_rng(1000 + seed)
+    res = int(rng.choice([32, 64, 128]))
+    levels = int(rng.choice([1, 2, 3]))
+    half = float(rng.choice([1.0, 1.5]))
+    flags = [dict(), dict(use_div_offsets=True), dict(use_time_embedding=True),
+             dict(use_time_embedding=True, use_time_attenuation=True, use_div_offsets=True)][int(rng.integers(4))]
+    cfg = dict(aabb=[-half] * 3 + [half] * 3, near_plane=float(rng.choice([0.0, 0.13])),
+               far_plane=float(rng.choice([1e10, 4.2])), moving_step=float(rng.choice([1e-4, 1.0 / 512])),
+               hash_max_res=int(rng.choice([512, 2048])), grid_resolution=res, grid_levels=levels,
+               render_step_size=float(rng.uniform(2e-3, 1.7e-2)), alpha_thre=float(rng.choice([0.0, 1e-2])),
+               cone_angle=float(rng.choice([0.0, 0.0037, 0.012])), bkgd=[float(x) for x in rng.uniform(0, 1, 3)],
+               opengl=bool(rng.integers(2)), camera_angle_x=float(rng.uniform(0.5, 1.1)),
+               radius=float(rng.choice([0.6 * half, 1.9 * half, 2.7 * half])), flags=flags)
+    S.CONFIGS["fuzz"] = cfg
+    try:
+        sc = S.make_scene("fuzz", 40, 30, "trained", azim_deg=float(rng.uniform(0, 360)), elev_deg=float(rng.uniform(-40, 60)),
+                          seed=seed, log2_hashmap_size=15, timestamp=float(rng.uniform(0, 1)))
+    finally:
+        del S.CONFIGS["fuzz"]
+    # irregular occupancy: sparse random cells plus the analytic shape, per level
+    b = sc["binaries"].copy()
+    b |= rng.uniform(size=b.shape) < 0.02
+    if seed % 3 == 0:
+        b[-1] = False                                        # an entirely empty (coarsest) level
+    sc["binaries"] = b
+    of, oest, f, est, rays, rk = _setup(oracle, sc)
+    max_samples = int(rng.choice([64, 300, 1024]))
+    trace = []
+    w_rgb, w_op, w_dp, w_total = oracle.render_image_test(max_samples, of, oest, sc["origins"], sc["viewdirs"],
+                                                          timestamps=sc["timestamps"], trace=trace, **sc["render"])
+    tracer = ops.FrameTracer(capacity=1100, with_events=False)
+    rgb, op, dp, total = render_image_test(max_samples, f, est, rays, timestamps=T(sc["timestamps"]), tracer=tracer, **rk)
+    assert total == w_total, (cfg, total, w_total)
+    assert tracer.iterations() == [dict(n_alive=t["n_alive"], n_samples=t["n_samples"], n_new=t["n_new"]) for t in trace]
+    assert_bitexact(N(rgb), w_rgb, f"rgb {cfg}")
+    assert_bitexact(N(dp), w_dp, f"depth {cfg}")
+    assert np.abs(N(op) - w_op).max() <= 1e-6
+
+
 @pytest.mark.parametrize("prec", ["f16x2", "f16"])
 @pytest.mark.parametrize("name,wh,kw", [("dnerf", (80, 60), {}), ("hypernerf", (48, 64), {}),
                                         ("dnerf", (80, 60), {"table_dtype": np.float16})])   # last: BASELINE config 5
