@@ -538,13 +538,10 @@ def test_render_image_test_parity(oracle, name, regime, wh):
     assert_bitexact(N(dp), w_dp, "depth (bit-exact)")
 
 
-@pytest.mark.parametrize("seed", range(int(__import__("os").environ.get("CED_FUZZ_SEEDS", "8"))))
-def test_render_image_test_random_configurations(oracle, seed):
-    """Fuzz over the knobs the three dataset configs do not vary together: grid resolution and level count, step size,
-    cone angle, near / far planes, alpha threshold, camera convention and distance (including a camera inside the
-    box), irregular occupancy, model flags.  The native frame loop against the oracle: schedule, counts, pixels."""
-    from ced_nerf_amd import ops, synthetic as S
-    from ced_nerf_amd.utils import render_image_test
+def _fuzz_scene(seed):
+    """A random configuration: grid resolution and level count, step size, cone angle, near / far planes, alpha
+    threshold, camera convention and distance (including a camera inside the box), irregular occupancy, model flags."""
+    from ced_nerf_amd import synthetic as S
     rng = np.random.default_rng(1000 + seed)
     res = int(rng.choice([32, 64, 128]))
     levels = int(rng.choice([1, 2, 3]))
@@ -570,6 +567,16 @@ def test_render_image_test_random_configurations(oracle, seed):
     if seed % 3 == 0:
         b[-1] = False                                        # an entirely empty (coarsest) level
     sc["binaries"] = b
+    return sc, cfg, rng
+
+
+@pytest.mark.parametrize("seed", range(int(__import__("os").environ.get("CED_FUZZ_SEEDS", "8"))))
+def test_render_image_test_random_configurations(oracle, seed):
+    """Fuzz over the knobs the three dataset configs do not vary together (see _fuzz_scene).  The native frame loop
+    against the oracle: schedule, counts, pixels."""
+    from ced_nerf_amd import ops
+    from ced_nerf_amd.utils import render_image_test
+    sc, cfg, rng = _fuzz_scene(seed)
     of, oest, f, est, rays, rk = _setup(oracle, sc)
     max_samples = int(rng.choice([64, 300, 1024]))
     trace = []
@@ -582,6 +589,19 @@ def test_render_image_test_random_configurations(oracle, seed):
     assert_bitexact(N(rgb), w_rgb, f"rgb {cfg}")
     assert_bitexact(N(dp), w_dp, f"depth {cfg}")
     assert np.abs(N(op) - w_op).max() <= 1e-6
+
+
+@pytest.mark.parametrize("seed", range(int(__import__("os").environ.get("CED_FUZZ_SEEDS", "6"))))
+def test_render_image_random_configurations(oracle, seed):
+    """The same fuzz through render_image (sampling -> visibility filter -> rendering, cednerf/utils.py:46-150)."""
+    from ced_nerf_amd.utils import render_image
+    sc, cfg, rng = _fuzz_scene(100 + seed)
+    of, oest, f, est, rays, rk = _setup(oracle, sc)
+    w = oracle.render_image(of, oest, sc["origins"], sc["viewdirs"], timestamps=sc["timestamps"], **sc["render"])
+    g = render_image(f, est, rays, timestamps=T(sc["timestamps"]), **rk)
+    assert g[3] == w[3], (cfg, g[3], w[3])
+    for i, nm in enumerate(("colors", "opacities", "depths")):
+        assert_bitexact(N(g[i]), w[i].reshape(N(g[i]).shape), f"{nm} {cfg}")
 
 
 @pytest.mark.parametrize("prec", ["f16x2", "f16"])
