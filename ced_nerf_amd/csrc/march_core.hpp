@@ -199,6 +199,12 @@ __device__ __forceinline__ int traverse_ray(const GridSpec &G, const float (&o)[
     float t_last = near;
     bool continuous = false;
     int n = 0;
+    // A segment that ends in empty cells owes one skip-march to its last empty boundary.  It is deferred to the next
+    // processed segment (or to the end of the call): the t_last sequence is the same, but a ray that LEAVES the
+    // occupied region -- and will be dead after this call of the frame renderer -- does not pay the closed-form
+    // skip (double-precision divisions, executed by the whole wave) for a termination plane nobody reads.
+    bool owed = false;
+    float owed_to = 0.0f;
     CED_MP(0)                       // [0] kernel prologue: ray loads
     for (int i = 0; i < 2 * n_grids - 1; ++i) {
         // Sample budget used up: later segments change nothing (the cell loop would not run and
@@ -218,6 +224,7 @@ __device__ __forceinline__ int traverse_ray(const GridSpec &G, const float (&o)[
         float this_tmax = fminf(ts_row[i + 1], far);
         if (this_tmin >= this_tmax) continue;
         CED_MP(1)                   // [1] segment selection
+        if (owed) { t_last = skip_march(t_last, owed_to, step_size, cone_angle); owed = false; }
         if (!continuous) t_last = skip_march(t_last, this_tmin, step_size, cone_angle);
         CED_MP(2)                   // [2] skip-march to the segment start
         const float *ab = G.aabbs + 6 * lvl;
@@ -330,9 +337,12 @@ __device__ __forceinline__ int traverse_ray(const GridSpec &G, const float (&o)[
             }
             CED_MP(4)
         }
-        if (has_pending) t_last = skip_march(t_last, pending, step_size, cone_angle);
+        if (has_pending) { owed = true; owed_to = pending; }
         CED_MP(2)
     }
+    // frame renderer (the same licence as its brick early-out): the termination plane of a ray that ends the call
+    // short of its budget is never read, so the owed skip is dropped; everyone else pays it here
+    if (owed && !(G.dilated_bricks != nullptr && limit > 0 && n < limit)) t_last = skip_march(t_last, owed_to, step_size, cone_angle);
     t_term = t_last;
     CED_MP(1)
 #ifdef CED_MARCH_PROFILE

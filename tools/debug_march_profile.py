@@ -15,6 +15,7 @@ rk = dict(sc["render"]); rk["render_bkgd"] = T(rk["render_bkgd"])
 rays = Rays(T(sc["origins"]), T(sc["viewdirs"])); ts = T(sc["timestamps"])
 L = _lib.lib()
 names = ["prologue", "segment select", "skip-march", "DDA set-up", "brick probes", "look-ahead DDA", "occupancy wait + emission", "reserve + copy-out"]
+prev = None
 for max_samples in (1, 2, 4, 7, 11, 17, 26, 41, 71, 132, 1024):      # cumulative: iteration k is the difference
     buf = (C.c_ulonglong * 16)()
     L.ced_debug_march_profile(None, 1)
@@ -24,3 +25,9 @@ for max_samples in (1, 2, 4, 7, 11, 17, 26, 41, 71, 132, 1024):      # cumulativ
     v = np.array(list(buf), np.float64)
     print(f"max_samples {max_samples:5d}: waves {int(v[8]):6d}  total Mcycles {v[:8].sum()/1e6:8.1f}  " +
           "  ".join(f"{n} {100*x/max(v[:8].sum(),1):.0f}%" for n, x in zip(names, v[:8])))
+    if prev is not None:
+        dv = v - prev
+        tot = max(dv[:8].sum(), 1)
+        print(f"      this iteration alone: waves {int(dv[8]):6d}, Mcycles {tot/1e6:7.1f}, per wave {tot/max(dv[8],1)/1e3:6.1f} k: " +
+              "  ".join(f"{n} {100*x/tot:.0f}%" for n, x in zip(names, dv[:8])))
+    prev = v
