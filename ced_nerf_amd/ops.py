@@ -269,6 +269,23 @@ def composite_backward(packed_info, t_starts, t_ends, sigmas, rgbs, d_color, d_o
     return d_sig, d_rgb
 
 
+def weight_grad(x, dy):
+    """ced_weight_grad: dW [n_out, n_in] = dy^T x over the sample stream (x [S, n_in], dy [S, n_out], fp32)."""
+    _chk(x, torch.float32, "x"); _chk(dy, torch.float32, "dy")
+    assert x.dim() == 2 and dy.dim() == 2 and x.shape[0] == dy.shape[0], "weight_grad: x [S, n_in], dy [S, n_out]"
+    n, n_in, n_out = x.shape[0], x.shape[1], dy.shape[1]
+    if x.data_ptr() % 16:
+        x = x.clone()
+    if dy.data_ptr() % 16:
+        dy = dy.clone()
+    dw = torch.empty((n_out, n_in), device=x.device, dtype=torch.float32)
+    nbytes = int(_lib.lib().ced_weight_grad_workspace_bytes(n, n_out, n_in))
+    ws = torch.empty((max(nbytes, 4) // 4,), device=x.device, dtype=torch.float32)
+    rc = _lib.lib().ced_weight_grad(n, _p(x), n_in, _p(dy), n_out, _p(dw), _p(ws), nbytes, _stream())
+    _lib.check(rc, "weight_grad")
+    return dw
+
+
 def composite_prefix_(packed_info, t_starts, t_ends, sigmas, rgbs, rgb, opacity, depth):
     _chk(packed_info, torch.int64, "packed_info"); _chk(rgbs, torch.float32, "rgbs")
     for nm, t in (("rgb", rgb), ("opacity", opacity), ("depth", depth)):

@@ -5,8 +5,9 @@ What runs where, for now:
   * hash-grid encode, forward and backward                    -> HIP  (ced_hash_encode / ced_hash_encode_backward)
   * compositing, forward and backward                         -> HIP  (render.rendering_train)
   * gradient-free densities of the sampling pass               -> HIP  (the fused inference kernel on the shared parameters)
-  * the three bias-free MLPs, forward and backward            -> plain library GEMMs through torch (rocBLAS); the
-    fused forward kernel of model.py has no backward yet.  Encodings and the small element-wise pieces are torch too.
+  * the three bias-free MLPs: y = x W^T and dx = dy W         -> plain library GEMMs through torch (rocBLAS);
+    dW = dy^T x (tiny tile, million-deep reduction)           -> HIP  (ced_weight_grad, csrc/wgrad.hip).
+    The fused forward kernel of model.py has no backward yet.  Encodings and the small element-wise pieces are torch.
 `TrainableField` keeps the parameter names and layout of `DNGPradianceField` (hash_table, xyz_wrap, mlp_base,
 mlp_head as W[out][in]), so `to_inference()` hands the trained weights to the fused kernels unchanged, and
 `tests/test_gpu_parity.py` checks that the two forwards agree.  Mirrors cednerf/model.py:354-488 (forward) and the
@@ -46,6 +47,23 @@ class _HashFn(torch.autograd.Function):
         return dx, grad_table, None
 
 
+class _LinearFn(torch.autograd.Function):
+    """y = x W^T of a bias-free layer.  The weight gradient dW = dy^T x -- a 64x64 tile reduced over ~1e6 samples,
+    which a library GEMM runs on a handful of workgroups -- goes through ced_weight_grad; y and dx stay library GEMMs."""
+
+    @staticmethod
+    def forward(ctx, x, w):
+        ctx.save_for_backward(x, w)
+        return x @ w.t()
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, w = ctx.saved_tensors
+        dx = dy @ w if ctx.needs_input_grad[0] else None
+        dw = ops.weight_grad(x.contiguous(), dy.float().contiguous()) if ctx.needs_input_grad[1] else None
+        return dx, dw
+
+
 class TrainableField(torch.nn.Module):
     """Differentiable DNGPradianceField (cednerf/model.py:97-488) with the inference module's parameters."""
 
@@ -71,11 +89,13 @@ class TrainableField(torch.nn.Module):
             self.time_encoder = SinusoidalEncoder(1, 0, 4, True)
             self.time_encoder_feat = SinusoidalEncoderWithExp(1, 0, 4, True)
 
-    @staticmethod
-    def _mlp(x, weights):
+    hip_weight_grad = True          # False: all three GEMMs of a layer through the library (A/B timing, tests)
+
+    def _mlp(self, x, weights):
+        lin = _LinearFn.apply if self.hip_weight_grad else (lambda a, w: a @ w.t())
         for w in weights[:-1]:
-            x = torch.relu(x @ w.t())
-        return x @ weights[-1].t()
+            x = torch.relu(lin(x, w))
+        return lin(x, weights[-1])
 
     def forward(self, positions: torch.Tensor, t: torch.Tensor, directions: torch.Tensor):
         """positions [N,3] world, t [N,1] in [0,1], directions [N,3] -> (rgb [N,3], sigma [N])."""

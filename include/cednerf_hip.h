@@ -220,6 +220,16 @@ int ced_composite_backward(int64_t n_rays, const int64_t *packed_info, const flo
                            const float *d_color, const float *d_opacity, const float *d_depth,
                            float *d_sigmas, float *d_rgbs, void *stream);
 
+/* Weight gradient of a bias-free dense layer over the sample stream:
+ *   dw[o][i] = sum_s dy[s][o] * x[s][i],   x [n, n_in], dy [n, n_out], dw [n_out, n_in], widths 1..64, all fp32,
+ * x and dy contiguous and 16-byte aligned.  Replaces the weight-gradient GEMM of tiny-cuda-nn's Network backward
+ * (modules of cednerf/model.py:200-222,280-309 under loss.backward(), train_real.py:414-419).  fp32 MFMA
+ * accumulation, two deterministic stages (per-workgroup partial tiles in `workspace`, then a fixed-order sum):
+ * reproducible run to run.  ced_weight_grad_workspace_bytes gives the scratch size for n samples. */
+int64_t ced_weight_grad_workspace_bytes(int64_t n, int32_t n_out, int32_t n_in);
+int ced_weight_grad(int64_t n, const float *x, int32_t n_in, const float *dy, int32_t n_out, float *dw,
+                    void *workspace, int64_t workspace_bytes, void *stream);
+
 /* ced_composite_prefix plus the per-iteration bookkeeping of cednerf/utils.py:301-307 in the same
  * launch: ray_mask[r] = opacity[r] <= opc_thres && count[r] == n_samples_iter, and
  * stats[0] += number of rays still alive, stats[1] += samples composited (device int64[2], the

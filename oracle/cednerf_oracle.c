@@ -765,6 +765,18 @@ void ced_o_composite_backward(int64_t n_rays, const int64_t *packed_info, const 
     }
 }
 
+/* Weight gradient of a bias-free dense layer, dw[o][i] = sum_s dy[s][o] x[s][i], in float64 (checker of
+ * ced_weight_grad; the GEMM tiny-cuda-nn runs for the modules of cednerf/model.py:200-222,280-309 in backward). */
+void ced_o_weight_grad(int64_t n, const float *x, int32_t n_in, const float *dy, int32_t n_out, double *dw)
+{
+    for (int64_t e = 0; e < (int64_t)n_out * n_in; ++e) dw[e] = 0.0;
+    for (int64_t s = 0; s < n; ++s)
+        for (int o = 0; o < n_out; ++o) {
+            double g = (double)dy[s * n_out + o];
+            for (int i = 0; i < n_in; ++i) dw[o * n_in + i] += g * (double)x[s * n_in + i];
+        }
+}
+
 /* render_visibility_from_density (inside OccGridEstimator.sampling, utils.py:115-125). */
 void ced_o_visibility(int64_t n_rays, const int64_t *packed_info, const float *t_starts,
                       const float *t_ends, const float *sigmas, float early_stop_eps, float alpha_thre,

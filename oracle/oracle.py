@@ -334,6 +334,14 @@ def composite_backward(packed_info, t_starts, t_ends, sigmas, rgbs, d_color, d_o
     return ds, dc
 
 
+def weight_grad(x, dy):
+    """dW [n_out, n_in] = dy^T x in float64 (checker of ced_weight_grad)."""
+    x = _f32(x); dy = _f32(dy)
+    dw = np.zeros((dy.shape[1], x.shape[1]), np.float64)
+    lib().ced_o_weight_grad(C.c_int64(x.shape[0]), _p(x), C.c_int32(x.shape[1]), _p(dy), C.c_int32(dy.shape[1]), _p(dw))
+    return dw
+
+
 def visibility_mask(t_starts, t_ends, sigmas, packed_info, early_stop_eps, alpha_thre):
     s = t_starts.shape[0]
     mask = np.empty((s,), np.uint8)

@@ -1041,6 +1041,72 @@ def test_trainable_field_matches_fused_kernel(oracle, case):
     assert ((sig_t[nz] - sig_f[nz]).abs() / sig_f[nz]).max().item() <= 2e-4
 
 
+WGRAD_SHAPES = [(64, 64), (64, 32), (6, 64), (16, 64), (64, 41), (64, 19), (3, 64), (1, 1), (33, 17), (48, 64), (64, 48)]
+
+
+@pytest.mark.parametrize("n", [0, 1, 3, 5, 1000, 70001])
+def test_weight_grad_matches_oracle(oracle, n):
+    """ced_weight_grad (dW = dy^T x, fp32 MFMA accumulation over the sample stream) against the oracle's float64 sum,
+    for every layer shape of the model and some ragged ones; sample counts that are not a multiple of the MFMA step
+    (4), fewer samples than one step, and none at all."""
+    from ced_nerf_amd import ops
+    rng = np.random.default_rng(100 + n)
+    for n_out, n_in in WGRAD_SHAPES:
+        x = rng.normal(size=(n, n_in)).astype(np.float32)
+        dy = (rng.normal(size=(n, n_out)) * rng.uniform(0.1, 3.0, size=(1, n_out))).astype(np.float32)
+        got = N(ops.weight_grad(T(x), T(dy)))
+        want = oracle.weight_grad(x, dy)
+        assert got.shape == (n_out, n_in)
+        bound = 4e-6 * (np.abs(dy).astype(np.float64).T @ np.abs(x).astype(np.float64)) + 1e-30
+        assert (np.abs(got - want) <= bound).all(), (n_out, n_in, np.abs(got - want).max())
+        if n == 0:
+            assert not got.any()
+
+
+def test_weight_grad_full_size_reproducible_and_rejects_bad_input(oracle):
+    """1.2 M samples x (64 x 64) -- the per-step size of a 262 k-ray training batch: two launches give the same bits
+    (no float atomics), the result matches a float64 library product, and bad widths / host tensors are refused."""
+    from ced_nerf_amd import ops
+    g = torch.Generator(device=DEV).manual_seed(7)
+    n = 1_200_003
+    x = torch.randn(n, 64, device=DEV, generator=g); dy = torch.randn(n, 64, device=DEV, generator=g)
+    a = ops.weight_grad(x, dy); b = ops.weight_grad(x, dy)
+    assert torch.equal(a, b)
+    want = dy.double().t() @ x.double()
+    assert (a.double() - want).abs().max().item() <= 2e-6 * float(n) ** 0.5 * 16
+    with pytest.raises(RuntimeError):
+        ops.weight_grad(torch.zeros(8, 65, device=DEV), torch.zeros(8, 4, device=DEV))
+    with pytest.raises(NotImplementedError):
+        ops.weight_grad(torch.zeros(8, 4), torch.zeros(8, 4))
+    odd = torch.randn(9, 19, device=DEV, generator=g)                           # a row-offset view: 76-byte offset
+    got = ops.weight_grad(odd[1:], torch.ones(8, 3, device=DEV))
+    assert torch.allclose(got, odd[1:].sum(0, keepdim=True).expand(3, 19), atol=1e-5)
+
+
+def test_trainable_field_gradients_hip_weight_grad_vs_library(oracle):
+    """The parameter gradients of a training loss with dW through ced_weight_grad equal the all-library ones."""
+    from ced_nerf_amd import synthetic as S
+    from ced_nerf_amd.train import TrainableField
+    p = S.init_field_params([-1.5, -1.5, -1.5, 1.5, 1.5, 1.5], 1e-3, 1024, 17, regime="init", seed=11, **dict(FIELD_CASES[0]))
+    p["hash"]["table"] = (p["hash"]["table"] * 3000.0).astype(np.float32)
+    tf = TrainableField(p, DEV)
+    rng = np.random.default_rng(6)
+    n = 30000
+    pos = T(rng.uniform(-1.4, 1.4, size=(n, 3)).astype(np.float32)); t = T(rng.uniform(0, 1, size=(n, 1)).astype(np.float32))
+    d = T(rng.normal(size=(n, 3)).astype(np.float32)); wr = T(rng.normal(size=(n, 3)).astype(np.float32))
+    grads = {}
+    for mode in (True, False):
+        tf.hip_weight_grad = mode
+        tf.zero_grad(set_to_none=True)
+        rgb, sig = tf(pos, t, d)
+        ((rgb * wr).sum() + sig.sum() * 0.1).backward()
+        grads[mode] = [q.grad.clone() for q in tf.parameters()]
+    assert TrainableField.hip_weight_grad is True
+    for (name, _), a, b in zip(tf.named_parameters(), grads[True], grads[False]):
+        assert a.abs().max().item() > 0, name
+        assert (a - b).abs().max().item() <= 2e-4 * b.abs().max().item(), (name, (a - b).abs().max().item(), b.abs().max().item())
+
+
 def test_training_steps_reduce_the_loss(oracle):
     """train.train_step end to end: HIP sampling, HIP hash forward/backward, library GEMMs, HIP compositing
     forward/backward, Adam.  A student whose hash table was damaged relearns a teacher's renders."""

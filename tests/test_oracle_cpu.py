@@ -316,3 +316,14 @@ def test_oracle_hash_backward_is_the_adjoint_of_the_forward(oracle):
             assert err < 2e-2, (l, a, err)
         _, dxs = of.hash_encode_backward(x, dyl, dx_scaled=True)          # times d pos / d x = scale
         assert np.allclose(dxs, dxl * np.float32(sc), rtol=1e-4, atol=1e-6 * float(np.abs(dxs).max()))
+
+
+def test_weight_grad_oracle_is_the_plain_sum(oracle):
+    """ced_o_weight_grad (checker of the training path's dW kernel) equals numpy's float64 dy^T x; empty input -> zeros."""
+    rng = np.random.default_rng(3)
+    for n, n_out, n_in in [(0, 4, 5), (1, 1, 1), (257, 6, 64), (1000, 64, 19)]:
+        x = rng.normal(size=(n, n_in)).astype(np.float32); dy = rng.normal(size=(n, n_out)).astype(np.float32)
+        got = oracle.weight_grad(x, dy)
+        want = dy.astype(np.float64).T @ x.astype(np.float64)
+        assert got.shape == (n_out, n_in)
+        np.testing.assert_allclose(got, want, rtol=1e-12, atol=1e-12)
