@@ -26,7 +26,7 @@ struct WgradArgs {
 };
 
 constexpr int kWgradWaves = 4;
-constexpr int kWgradMaxBlocks = 1024;
+constexpr int kWgradMaxBlocks = 768;          // three 4-wave workgroups per CU: all resident at once
 
 template <int NB>
 __device__ __forceinline__ void load_operands(const float *row, int first, int dim, bool valid, float (&v)[NB])
@@ -63,15 +63,19 @@ __global__ __launch_bounds__(kWgradWaves * 64) void wgrad_partial_kernel(WgradAr
 #pragma unroll
         for (int ib = 0; ib < NBI; ++ib) acc[nb][ib] = wf4{0.f, 0.f, 0.f, 0.f};
 
-    const int64_t n_steps = (A.n + 3) / 4;                       // one MFMA step = 4 samples (k = lane >> 4)
-    const int64_t stride = (int64_t)gridDim.x * kWgradWaves;
+    // one MFMA step = 4 samples (k = lane >> 4).  A workgroup owns a contiguous range of steps and its four waves
+    // interleave inside it, so the workgroup streams two contiguous spans (x and dy) instead of striding by megabytes.
+    const int64_t n_steps = (A.n + 3) / 4;
+    const int64_t per_block = (n_steps + gridDim.x - 1) / gridDim.x;
+    const int64_t block_end = min(n_steps, (int64_t)(blockIdx.x + 1) * per_block);
+    constexpr int64_t stride = kWgradWaves;
     constexpr int UNROLL = 4;
-    for (int64_t step0 = (int64_t)blockIdx.x * kWgradWaves + wave; step0 < n_steps; step0 += stride * UNROLL) {
+    for (int64_t step0 = (int64_t)blockIdx.x * per_block + wave; step0 < block_end; step0 += stride * UNROLL) {
         float a[UNROLL][NBO], b[UNROLL][NBI];
 #pragma unroll
         for (int u = 0; u < UNROLL; ++u) {
             const int64_t s = (step0 + u * stride) * 4 + kk;
-            const bool valid = s < A.n;
+            const bool valid = step0 + u * stride < block_end && s < A.n;
             const int64_t sc = valid ? s : 0;
             load_operands<NBO>(A.dy + sc * A.n_out, NBO * c, A.n_out, valid, a[u]);
             load_operands<NBI>(A.x + sc * A.n_in, NBI * c, A.n_in, valid, b[u]);
@@ -112,17 +116,34 @@ __global__ __launch_bounds__(kWgradWaves * 64) void wgrad_partial_kernel(WgradAr
     }
 }
 
-// dW[e] = partial[0][e] + partial[1][e] + ... (four interleaved chains per element, combined in fixed order)
-__global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float *partial, int n_blocks, int n_elems, float *dw)
+// dW[e] = sum_b partial[b][e]: 16 interleaved chains per element (chain q takes b = q, q+16, ... in ascending order,
+// loads issued 8 at a time), combined in ascending q -- a fixed order, so the sum is reproducible.
+constexpr int kReduceChains = 16;
+__global__ __launch_bounds__(64 * kReduceChains) void wgrad_reduce_kernel(const float *partial, int n_blocks, int n_elems, float *dw)
 {
-    __shared__ float red[4][64];
-    const int e = blockIdx.x * 64 + (threadIdx.x & 63), q = threadIdx.x >> 6;
+    __shared__ float red[kReduceChains][64];
+    const int col = threadIdx.x & 63, q = threadIdx.x >> 6;
+    const int e = blockIdx.x * 64 + col;
     float sum = 0.0f;
-    if (e < n_elems)
-        for (int b = q; b < n_blocks; b += 4) sum += partial[(int64_t)b * n_elems + e];
-    red[q][threadIdx.x & 63] = sum;
+    if (e < n_elems) {
+        int b = q;
+        for (; b + 7 * kReduceChains < n_blocks; b += 8 * kReduceChains) {
+            float v[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) v[u] = partial[(int64_t)(b + u * kReduceChains) * n_elems + e];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) sum += v[u];
+        }
+        for (; b < n_blocks; b += kReduceChains) sum += partial[(int64_t)b * n_elems + e];
+    }
+    red[q][col] = sum;
     __syncthreads();
-    if (q == 0 && e < n_elems) dw[e] = ((red[0][threadIdx.x] + red[1][threadIdx.x]) + red[2][threadIdx.x]) + red[3][threadIdx.x];
+    if (q == 0 && e < n_elems) {
+        float total = red[0][col];
+#pragma unroll
+        for (int k = 1; k < kReduceChains; ++k) total += red[k][col];
+        dw[e] = total;
+    }
 }
 
 static int wgrad_blocks(int64_t n)
@@ -185,7 +206,7 @@ extern "C" int ced_weight_grad(int64_t n, const float *x, int32_t n_in, const fl
     int rc = ced::check_launch("weight_grad (partial)");
     if (rc != CED_OK) return rc;
     const int n_elems = n_out * n_in;
-    hipLaunchKernelGGL(ced::wgrad_reduce_kernel, dim3((n_elems + 63) / 64), dim3(256), 0, st, (const float *)workspace, blocks,
+    hipLaunchKernelGGL(ced::wgrad_reduce_kernel, dim3((n_elems + 63) / 64), dim3(64 * ced::kReduceChains), 0, st, (const float *)workspace, blocks,
                        n_elems, dw);
     return ced::check_launch("weight_grad (reduce)");
 }
