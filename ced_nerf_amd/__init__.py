@@ -10,7 +10,7 @@ from . import encoder, hashgrid, synthetic  # noqa: F401  (no GPU / native code 
 
 def __getattr__(name):
     # torch-facing modules are imported lazily so that `import ced_nerf_amd` stays cheap
-    if name in ("ops", "nerfacc_api", "model", "render", "utils", "dist", "_lib", "cameras", "train", "profiling"):
+    if name in ("ops", "nerfacc_api", "model", "render", "utils", "dist", "_lib", "cameras", "train", "profiling", "video"):
         import importlib
         return importlib.import_module("." + name, __name__)
     raise AttributeError(name)

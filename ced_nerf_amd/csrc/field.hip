@@ -668,7 +668,7 @@ extern "C" int ced_set_option(const char *key, int value)
         return CED_OK;
     }
     if (strcmp(key, "field_max_blocks") == 0) {
-        CED_REQUIRE(value >= 1 && value <= 256, "set_option: field_max_blocks must be 1..256");
+        CED_REQUIRE(value >= 1 && value <= 65536, "set_option: field_max_blocks must be 1..65536");
         ced::g_field_max_blocks = value;
         return CED_OK;
     }

@@ -17,8 +17,21 @@ import torch.distributed as dist
 TILE = 8    # pixels; 8x8 tiles dealt round-robin balance the spatially clustered sample density
 
 
+_assignment_cache: Dict = {}
+
+
 def tile_cyclic_assignment(n_frames: int, height: int, width: int, world: int, tile: int = TILE):
-    """Returns (owner[n_rays] int32, per-rank lists of flat ray ids in tile-raster order)."""
+    """Returns (owner[n_rays] int32, per-rank lists of flat ray ids in tile-raster order).  Cached per shape: a video
+    re-deals every frame's rays the same way."""
+    key = (n_frames, height, width, world, tile)
+    if key not in _assignment_cache:
+        if len(_assignment_cache) > 16:
+            _assignment_cache.clear()
+        _assignment_cache[key] = _tile_cyclic_assignment(n_frames, height, width, world, tile)
+    return _assignment_cache[key]
+
+
+def _tile_cyclic_assignment(n_frames: int, height: int, width: int, world: int, tile: int):
     ty = (np.arange(height) // tile)[:, None]
     tx = (np.arange(width) // tile)[None, :]
     tiles_x = (width + tile - 1) // tile
@@ -64,8 +77,13 @@ class ShardedRenderer:
     def set_rays(self, origins: torch.Tensor, viewdirs: torch.Tensor) -> None:
         assert origins.ndim == 4 and origins.shape == viewdirs.shape, "rays must be [F,H,W,3]"
         F, H, W, _ = origins.shape
-        self.shape = (F, H, W)
         o = origins.reshape(-1, 3); d = viewdirs.reshape(-1, 3)
+        if self.shape == (F, H, W) and getattr(self, "_ray_index", None) is not None and self._ray_index.device == o.device:
+            # same image shape as last time (the next frame of a video): the index tensors are already on the device
+            self.local_o, self.local_d = o[self._ray_index].contiguous(), d[self._ray_index].contiguous()
+            return
+        self.shape = (F, H, W)
+        self._ray_index = None
         if self.world == 1 and not self.force_collective:
             self.n_local = self.n_pad = o.shape[0]
             self.gather_index = None
@@ -76,6 +94,7 @@ class ShardedRenderer:
                 inv = torch.empty_like(order)
                 inv[order] = torch.arange(order.numel(), device=o.device)
                 self.unpermute = inv
+                self._ray_index = order
             else:
                 self.local_o, self.local_d = o.contiguous(), d.contiguous()
                 self.unpermute = None
@@ -86,6 +105,7 @@ class ShardedRenderer:
         self.n_local = len(mine)
         idx = np.concatenate([mine, np.repeat(mine[-1:], self.n_pad - len(mine))]) if len(mine) < self.n_pad else mine
         idx_t = torch.from_numpy(idx.astype(np.int64)).to(o.device)
+        self._ray_index = idx_t
         self.local_o = o[idx_t].contiguous()
         self.local_d = d[idx_t].contiguous()
         # destination (flat ray id) of every gathered row; padded rows go to a scratch slot at the end
@@ -224,7 +244,9 @@ class PipelinedRenderer:
         steps: every lane renders its frame n_steps times back to back, so a lane that finishes early starts its next
         frame instead of waiting for the slowest one (a video is a stream of frames).  Gathers are issued by the
         calling thread in (step, lane) order -- the same order on every rank -- as the frames complete.
-        `before_frame(lane_index, step)` runs on the lane's thread before each frame (e.g. to swap tracers).
+        `before_frame(lane_index, step)` runs on the lane's thread (with the lane's stream current) before each frame,
+        e.g. to swap tracers or to hand the lane the rays of its next frame.  `timestamps` may be a callable
+        `(lane_index, step) -> tensor` for per-frame times.  An exception on a lane's thread is re-raised here.
         Returns a list (per step) of lists (per lane) of `gather` results."""
         import queue
         L = len(self.lanes)
@@ -235,10 +257,21 @@ class PipelinedRenderer:
         done = [[queue.Queue(maxsize=1) for _ in range(L)] for _ in range(n_steps)]
 
         def work(i):
-            for step in range(n_steps):
-                if before_frame is not None:
-                    before_frame(i, step)
-                done[step][i].put(self._lane(i, timestamps))
+            step = 0
+            try:
+                for step in range(n_steps):
+                    if before_frame is not None:
+                        if self.streams[i] is not None:
+                            with torch.cuda.stream(self.streams[i]):
+                                before_frame(i, step)
+                        else:
+                            before_frame(i, step)
+                    ts = timestamps(i, step) if callable(timestamps) else timestamps
+                    done[step][i].put(self._lane(i, ts))
+            except BaseException as e:           # hand the failure to the collecting thread instead of leaving it waiting
+                for s in range(step, n_steps):
+                    if done[s][i].empty():
+                        done[s][i].put(e)
 
         if self.pool is None:
             work(0)
@@ -252,6 +285,10 @@ class PipelinedRenderer:
             row = []
             for i, lane in enumerate(self.lanes):
                 loc = done[step][i].get()
+                if isinstance(loc, BaseException):
+                    for t in threads:
+                        t.result()
+                    raise loc
                 if self.async_gather and self.streams[0] is not None:
                     with torch.cuda.stream(self.comm_stream):
                         self.comm_stream.wait_stream(self.streams[i])

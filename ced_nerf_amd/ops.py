@@ -269,6 +269,32 @@ def composite_backward(packed_info, t_starts, t_ends, sigmas, rgbs, d_color, d_o
     return d_sig, d_rgb
 
 
+def frame_to_rgb8(rgb, flip_w: bool = True):
+    """ced_frame_to_rgb8: [H,W,3] float colours -> [H,W,3] uint8 (x 255, truncated), flipped along the width as the
+    reference's video frames are (train_real.py:556)."""
+    _chk(rgb, torch.float32, "rgb")
+    assert rgb.dim() == 3 and rgb.shape[2] == 3, "frame_to_rgb8: rgb [H,W,3]"
+    out = torch.empty(rgb.shape, device=rgb.device, dtype=torch.uint8)
+    _lib.check(_lib.lib().ced_frame_to_rgb8(rgb.shape[0], rgb.shape[1], _p(rgb), int(bool(flip_w)), _p(out), _stream()),
+               "frame_to_rgb8")
+    return out
+
+
+def depth_to_u8(depth, flip_w: bool = True):
+    """ced_depth_to_u8: [H,W] (or [H,W,1]) depths -> [H,W] uint8 of the min-max normalised image (depth2img of
+    train_real.py:38-41 before cv2's colour-map lookup)."""
+    _chk(depth, torch.float32, "depth")
+    if depth.dim() == 3:
+        assert depth.shape[2] == 1
+        depth = depth[..., 0]
+    assert depth.dim() == 2, "depth_to_u8: depth [H,W]"
+    out = torch.empty(depth.shape, device=depth.device, dtype=torch.uint8)
+    ws = torch.empty((2,), device=depth.device, dtype=torch.int32)
+    _lib.check(_lib.lib().ced_depth_to_u8(depth.shape[0], depth.shape[1], _p(depth), int(bool(flip_w)), _p(out), _p(ws),
+                                          _stream()), "depth_to_u8")
+    return out
+
+
 def weight_grad(x, dy):
     """ced_weight_grad: dW [n_out, n_in] = dy^T x over the sample stream (x [S, n_in], dy [S, n_out], fp32)."""
     _chk(x, torch.float32, "x"); _chk(dy, torch.float32, "dy")

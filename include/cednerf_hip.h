@@ -226,6 +226,15 @@ int ced_composite_backward(int64_t n_rays, const int64_t *packed_info, const flo
  * (modules of cednerf/model.py:200-222,280-309 under loss.backward(), train_real.py:414-419).  fp32 MFMA
  * accumulation, two deterministic stages (per-workgroup partial tiles in `workspace`, then a fixed-order sum):
  * reproducible run to run.  ced_weight_grad_workspace_bytes gives the scratch size for n samples. */
+/* The 8-bit frames of the reference's video step, on the device:
+ * ced_frame_to_rgb8: out[y][x'][c] = uint8(rgb[y][x][c] * 255), x' = width-1-x when flip_w
+ *   (np.flip(rgb * 255, axis=1).astype(np.uint8), train_real.py:556); rgb [H,W,3] f32, out [H,W,3] u8.
+ * ced_depth_to_u8: out = uint8((depth - min) / (max - min) * 255) over the image (depth2img before the colour-map
+ *   lookup, train_real.py:38-41), same flip; depth [H,W] f32, out [H,W] u8, workspace = 8 bytes of device memory. */
+int ced_frame_to_rgb8(int32_t height, int32_t width, const float *rgb, int32_t flip_w, uint8_t *out, void *stream);
+int ced_depth_to_u8(int32_t height, int32_t width, const float *depth, int32_t flip_w, uint8_t *out,
+                    void *workspace, void *stream);
+
 int64_t ced_weight_grad_workspace_bytes(int64_t n, int32_t n_out, int32_t n_in);
 int ced_weight_grad(int64_t n, const float *x, int32_t n_in, const float *dy, int32_t n_out, float *dw,
                     void *workspace, int64_t workspace_bytes, void *stream);

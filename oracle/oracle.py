@@ -334,6 +334,21 @@ def composite_backward(packed_info, t_starts, t_ends, sigmas, rgbs, d_color, d_o
     return ds, dc
 
 
+def frame_to_rgb8(rgb, flip_w=True):
+    """train_real.py:556: np.flip(rgb * 255, axis=1).astype(np.uint8) (float32 product, truncation)."""
+    v = _f32(rgb) * np.float32(255.0)
+    return (np.flip(v, axis=1) if flip_w else v).astype(np.uint8)
+
+
+def depth_to_u8(depth, flip_w=True):
+    """depth2img (train_real.py:38-41) up to the colour-map lookup: min-max normalise, x 255, uint8; flipped as the
+    video frames are (train_real.py:557)."""
+    d = _f32(depth)
+    d = (d - d.min()) / (d.max() - d.min())
+    v = d * np.float32(255.0)
+    return (np.flip(v, axis=1) if flip_w else v).astype(np.uint8)
+
+
 def weight_grad(x, dy):
     """dW [n_out, n_in] = dy^T x in float64 (checker of ced_weight_grad)."""
     x = _f32(x); dy = _f32(dy)

@@ -870,6 +870,78 @@ def test_pipelined_frames_equal_sequential_frames(oracle, full_frame):
         assert out["total_samples"] == want[3] and torch.equal(out["rgb"][0], want[0])
 
 
+def test_frame_to_uint8_bitexact(oracle):
+    """the 8-bit frames of the video step (train_real.py:556-557) -- colours x 255 truncated and
+    flipped along the width, depth min-max normalised -- bit-exact against the numpy statement, for ragged sizes,
+    negative depths, and without the flip."""
+    from ced_nerf_amd import ops
+    rng = np.random.default_rng(31)
+    for (H, W) in [(1, 1), (7, 13), (72, 96), (600, 801)]:
+        rgb = rng.uniform(0, 1, size=(H, W, 3)).astype(np.float32)
+        rgb.reshape(-1)[:: 17] = 1.0; rgb.reshape(-1)[1:: 29] = 0.0
+        depth = (rng.uniform(-2, 6, size=(H, W)) ** 2).astype(np.float32) - np.float32(1.5)
+        if H * W == 1:
+            depth[:] = 2.0                                   # constant image: 0/0 -> 0
+        for flip in (True, False):
+            got = N(ops.frame_to_rgb8(T(rgb), flip)); want = oracle.frame_to_rgb8(rgb, flip)
+            assert got.dtype == np.uint8 and got.shape == (H, W, 3)
+            assert_bitexact(got, want, f"rgb8 {H}x{W} flip={flip}")
+            got_d = N(ops.depth_to_u8(T(depth), flip))
+            if H * W == 1:
+                assert got_d.item() == 0
+                continue
+            assert_bitexact(got_d, oracle.depth_to_u8(depth, flip), f"depth8 {H}x{W} flip={flip}")
+            assert got_d.min() == 0 and got_d.max() == 255
+            assert_bitexact(N(ops.depth_to_u8(T(depth)[..., None].contiguous(), flip)), got_d, "depth [H,W,1]")
+    with pytest.raises(NotImplementedError):
+        ops.frame_to_rgb8(torch.zeros(4, 4, 3))
+
+
+def test_render_video_equals_frames_rendered_alone(oracle):
+    """video.render_video: a camera path with per-frame times streamed through frames in flight, rays generated on
+    the device on each lane's stream; every frame equals render_image_test of that frame alone, and the uint8 frames
+    are the numpy conversion of those floats.  5 frames over 3 lanes (the last step is ragged), then 1 lane."""
+    from ced_nerf_amd import cameras, synthetic as S
+    from ced_nerf_amd.model import DNGPradianceField
+    from ced_nerf_amd.nerfacc_api import OccGridEstimator
+    from ced_nerf_amd.utils import render_image_test
+    from ced_nerf_amd.video import render_video
+    W, H = 96, 72
+    sc = _scene("dnerf", W, H, "trained", log2_hashmap_size=15)
+    cfg = sc["cfg"]
+    f = DNGPradianceField.from_params(sc["params"], DEV).eval()
+    est = OccGridEstimator(cfg["aabb"], cfg["grid_resolution"], cfg["grid_levels"]).to(DEV)
+    est.set_binaries(T(sc["binaries"]))
+    rk = dict(sc["render"]); rk["render_bkgd"] = T(rk["render_bkgd"])
+    focal = 0.5 * W / np.tan(0.5 * cfg["camera_angle_x"])
+    K = np.array([[focal, 0, W / 2.0], [0, focal, H / 2.0], [0, 0, 1]], np.float32)
+    n_frames = 5
+    poses = [S.look_at_c2w(cfg["radius"], 30.0, 15.0 + 20.0 * k, cfg["opengl"]) for k in range(n_frames)]
+    times = [torch.tensor([[k / (n_frames - 1.0)]], device=DEV) for k in range(n_frames)]
+    rays_of = lambda i: cameras.pinhole_rays(K, poses[i], W, H, cfg["opengl"], device=DEV)
+    alone = [render_image_test(1024, f, est, rays_of(i), timestamps=times[i], **rk) for i in range(n_frames)]
+    assert not torch.equal(alone[0][0], alone[1][0])
+    for in_flight in (3, 1):
+        frames = render_video(f, est, rays_of, lambda i: times[i], n_frames, render_kwargs=rk, frames_in_flight=in_flight,
+                              keep_float=True)
+        torch.cuda.synchronize()
+        assert len(frames) == n_frames
+        for fr, want in zip(frames, alone):
+            assert fr["n_samples"] == want[3] and want[3] > 1000
+            assert torch.equal(fr["rgb_f32"], want[0]) and torch.equal(fr["depth_f32"], want[2])
+            assert_bitexact(N(fr["rgb"]), oracle.frame_to_rgb8(N(want[0])), "video rgb8")
+            assert_bitexact(N(fr["depth"]), oracle.depth_to_u8(N(want[2])[..., 0]), "video depth8")
+    host = render_video(f, est, rays_of, lambda i: times[i], 2, render_kwargs=rk, to_host=True)
+    assert isinstance(host[0]["rgb"], np.ndarray) and host[1]["rgb"].shape == (H, W, 3)
+    # a failure on a lane's thread surfaces as an exception instead of a hang
+    def bad_rays(i):
+        if i == 3:
+            raise ValueError("no such pose")
+        return rays_of(i)
+    with pytest.raises(ValueError):
+        render_video(f, est, bad_rays, lambda i: times[i], n_frames, render_kwargs=rk)
+
+
 def test_occupancy_grid_update_parity(oracle):
     """OccGridEstimator._update (positions -> density*step -> EMA max -> threshold) with
     the random draws injected; occs bit-exact against the oracle, binaries equal away from the threshold."""

@@ -327,3 +327,15 @@ def test_weight_grad_oracle_is_the_plain_sum(oracle):
         want = dy.astype(np.float64).T @ x.astype(np.float64)
         assert got.shape == (n_out, n_in)
         np.testing.assert_allclose(got, want, rtol=1e-12, atol=1e-12)
+
+
+def test_frame_conversion_oracle_known_answers(oracle):
+    """The 8-bit frame conversions of the video step (train_real.py:38-41,556-557): truncation, the width flip, the
+    min-max normalisation."""
+    rgb = np.array([[[0.0, 0.5, 1.0], [0.999, 0.25, 0.003]]], np.float32)               # [1,2,3]
+    got = oracle.frame_to_rgb8(rgb)
+    assert got.tolist() == [[[254, 63, 0], [0, 127, 255]]]
+    assert oracle.frame_to_rgb8(rgb, False).tolist() == [[[0, 127, 255], [254, 63, 0]]]
+    d = np.array([[1.0, 2.0, 3.0, 5.0]], np.float32)
+    assert oracle.depth_to_u8(d, False).tolist() == [[0, 63, 127, 255]]
+    assert oracle.depth_to_u8(d).tolist() == [[255, 127, 63, 0]]
