@@ -126,6 +126,11 @@ def lib() -> C.CDLL:
             fn.restype = res
             fn.argtypes = args
         _lib = handle
+        # tuning knobs from the environment: CED_OPTIONS="field_spread_tiles=0,march_early_out=1" (ced_set_option)
+        for item in filter(None, os.environ.get("CED_OPTIONS", "").split(",")):
+            key, _, value = item.partition("=")
+            if handle.ced_set_option(key.strip().encode(), int(value)) != 0:
+                raise RuntimeError(f"CED_OPTIONS: {handle.ced_last_error_string().decode()}")
     return _lib
 
 
