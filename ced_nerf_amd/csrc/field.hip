@@ -339,7 +339,6 @@ __global__ __launch_bounds__(THREADS) void field_kernel(FieldArgs A)
         to_operand<4, true, NT>(D, B);
         mlp_layer<16, 1, NT>(lw + BL::B1, lane, B, D);
 
-        const bool store_lane = (g == 0);
 #pragma unroll
         for (int j = 0; j < NT; ++j) {
             const int64_t s = tile * TILE + 16 * j + c;
@@ -391,14 +390,16 @@ __global__ __launch_bounds__(THREADS) void field_kernel(FieldArgs A)
 #pragma unroll
             for (int j = 0; j < NT; ++j) {
                 const int64_t s = tile * TILE + 16 * j + c;
-                float o3[3];
-#pragma unroll
-                for (int a = 0; a < 3; ++a) o3[a] = 1.0f / (1.0f + det_expf(-D[j][0][a]));
-                if (store_lane && s < n_eff) {
-                    A.rgb[3 * s] = o3[0];
-                    A.rgb[3 * s + 1] = o3[1];
-                    A.rgb[3 * s + 2] = o3[2];
-                }
+                // the packer put colour channel a on accumulator row 4a = (lane group a, register 0): every lane
+                // evaluates ONE sigmoid (its group's channel) instead of three of which only group 0's were kept
+                const float o1 = 1.0f / (1.0f + det_expf(-D[j][0][0]));
+                // (re-derived from the lane id here rather than kept live across the tile: the kernel sits at the
+                //  168-register limit of three waves per SIMD)
+                int lane_now = (int)threadIdx.x;
+                asm volatile("" : "+v"(lane_now));
+                const int g_now = (lane_now >> 4) & 3;
+                const int64_t s_now = tile * TILE + 16 * j + (lane_now & 15);
+                if (g_now < 3 && s_now < n_eff) A.rgb[3 * s_now + g_now] = o1;
             }
         }
     }
@@ -713,7 +714,8 @@ extern "C" int ced_pack_field_weights(int use_div_offsets, int time_mode, const 
     const bool te = time_mode != 0;
     const int64_t total = ced_packed_weight_floats(use_div_offsets, time_mode);
     for (int64_t i = 0; i < total; ++i) out[i] = 0.0f;
-    struct L { const float *w; int n_out, n_in, nb, ks, off; int placement; };   // 0 natural, 1 hidden, 2 base-out
+    // placement: 0 natural, 1 hidden, 2 base-out, 3 one neuron per lane group (row 4a = neuron a)
+    struct L { const float *w; int n_out, n_in, nb, ks, off; int placement; };
     const int base_in = te ? 41 : 32;
     const int n_mo = use_div_offsets ? 6 : 3;
     const int ksb0 = te ? 11 : 8;
@@ -732,7 +734,7 @@ extern "C" int ced_pack_field_weights(int use_div_offsets, int time_mode, const 
         { m_w2, 64, 64, 4, 16, offs[2], 1 },     { m_w3, n_mo, 64, 1, 16, offs[3], 0 },
         { b_w0, 64, base_in, 4, ksb0, offs[4], 1 }, { b_w1, 16, 64, 1, 16, offs[5], 2 },
         { h_w0, 64, 19, 4, 5, offs[6], 1 },      { h_w1, 64, 64, 4, 16, offs[7], 1 },
-        { h_w2, 3, 64, 1, 16, offs[8], 0 },
+        { h_w2, 3, 64, 1, 16, offs[8], 3 },
     };
     for (const L &l : layers) {
         const int ks4 = ced::ks4_of(l.ks);
@@ -742,6 +744,7 @@ extern "C" int ced_pack_field_weights(int use_div_offsets, int time_mode, const 
             int neuron = p;
             if (l.placement == 1) neuron = (p & ~15) | ((p & 3) << 2) | ((p >> 2) & 3);
             else if (l.placement == 2) neuron = ced::base_out_neuron(p);
+            else if (l.placement == 3) neuron = (p & 3) ? l.n_out : (p >> 2);
             if (neuron >= l.n_out) continue;
             for (int k = 0; k < l.ks * 4; ++k) {
                 if (k >= l.n_in) continue;

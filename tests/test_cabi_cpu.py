@@ -83,6 +83,8 @@ def _row_neuron(p, placement):
         return 16 * nb + 4 * r + g
     if placement == "base_out":                  # neuron 0 = raw density, n >= 1 = head input 3 + n
         return 4 * r + g - 3 if r else (13 + g if g < 3 else 0)
+    if placement == "per_group":                 # colour channel a on row 4a = (lane group a, register 0)
+        return g if (r == 0 and nb == 0) else 1 << 30
     return p
 
 
@@ -113,7 +115,7 @@ def test_pack_field_weights_layout(div, tm):
     parts = [_ref_pack(p["xyz_wrap"][0], 64, 8, H), _ref_pack(p["xyz_wrap"][1], 64, 16, H), _ref_pack(p["xyz_wrap"][2], 64, 16, H),
              _ref_pack(p["xyz_wrap"][3], 16, 16), _ref_pack(p["mlp_base"][0], 64, ksb0, H),
              _ref_pack(p["mlp_base"][1], 16, 16, "base_out"), _ref_pack(p["mlp_head"][0], 64, 5, H),
-             _ref_pack(p["mlp_head"][1], 64, 16, H), _ref_pack(p["mlp_head"][2], 16, 16)]
+             _ref_pack(p["mlp_head"][1], 64, 16, H), _ref_pack(p["mlp_head"][2], 16, 16, "per_group")]
     assert sorted(_row_neuron(q, "base_out") for q in range(16)) == list(range(16))
     assert sorted(_row_neuron(q, H) for q in range(64)) == list(range(64))
     want = np.concatenate(parts)
