@@ -366,17 +366,13 @@ __global__ __launch_bounds__(THREADS) void field_kernel(FieldArgs A)
                 for (int a = 0; a < 3; ++a)
                     dv[a] = A.rays_mode ? A.rays_d[3 * ridx[j] + a] : A.dir[3 * sidx[j] + a];
                 const float nrm = __builtin_sqrtf((dv[0] * dv[0] + dv[1] * dv[1]) + dv[2] * dv[2]);
-                float v[3];
-#pragma unroll
-                for (int a = 0; a < 3; ++a) {
-                    const float u = (dv[a] / nrm + 1.0f) / 2.0f;
-                    v[a] = u * 2.0f - 1.0f;
-                }
-                float sh = 0.28209479177387814f;
-                sh = (g == 1) ? (-0.48860251190291987f * v[1]) : sh;
-                sh = (g == 2) ? (0.48860251190291987f * v[2]) : sh;
-                sh = (g == 3) ? (-0.48860251190291987f * v[0]) : sh;
-                B[j][0] = sh;
+                // lane group g feeds SH coefficient g: only that one direction component is normalised here
+                // (Y00 const, Y1-1 ~ -y, Y10 ~ z, Y11 ~ -x; tcnn maps the unit vector to [0,1] and back)
+                const float comp = (g == 1) ? dv[1] : (g == 2) ? dv[2] : dv[0];
+                const float u = (comp / nrm + 1.0f) / 2.0f;
+                const float vv = u * 2.0f - 1.0f;
+                const float coef = (g == 2) ? 0.48860251190291987f : -0.48860251190291987f;
+                B[j][0] = (g == 0) ? 0.28209479177387814f : coef * vv;
                 B[j][1] = D[j][0][1];
                 B[j][2] = D[j][0][2];
                 B[j][3] = D[j][0][3];
