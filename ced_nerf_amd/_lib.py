@@ -92,6 +92,10 @@ PROTOTYPES = {
     "ced_render_image_test": (C.c_int, [C.POINTER(FieldDesc), _i64, _vp, _vp, _vp, _i32, _i32, _vp, _f, _f, _f, _f, _f,
                                         _i32, _vp, _i32, _vp, _vp, _vp, _vp, _vp, _i64, _vp, C.POINTER(_i64),
                                         C.POINTER(FrameTrace), _vp, _vp]),
+    "ced_render_frames_test_workspace_bytes": (_i64, [_i32, _i64, _i32, _i32, _f, _i32]),
+    "ced_render_frames_test": (C.c_int, [C.POINTER(FieldDesc), _i32, _i64, _vp, _vp, _vp, _i32, _i32, _vp, _f, _f, _f, _f,
+                                         _f, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _vp, C.POINTER(_i64),
+                                         C.POINTER(FrameTrace), _vp, _vp]),
 }
 
 

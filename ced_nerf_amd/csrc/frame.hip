@@ -50,6 +50,36 @@ __device__ __forceinline__ bool slab_test(const float o[3], const float inv_d[3]
 }
 
 constexpr int kMaxGrids = 8;
+constexpr int kMaxFrames = 8;       // frames rendered by one call (ced_render_frames_test)
+
+// Several frames in one call: the rays of all frames are one array (frame f owns ray ids [f*rays_per_frame,
+// (f+1)*rays_per_frame)), every frame keeps its OWN schedule (N_samples = clamp(N_rays // N_alive, min, 64) on its
+// own counts, its own loop end) and its own alive list; a launch covers the frames' alive rays back to back, each
+// frame's slot range starting at a multiple of 256 so that a workgroup never straddles two frames.
+struct BatchMap {
+    int n_frames;
+    int rays_per_frame;
+    int base[kMaxFrames];       // first slot of the frame in this launch
+    int count[kMaxFrames];      // alive rays of the frame in this launch (0: the frame has finished)
+    int limit[kMaxFrames];      // the frame's N_samples in this iteration
+    int last[kMaxFrames];       // the frame's loop ends after this iteration (max_samples reached)
+};
+
+// frame of the workgroup whose first slot is s0 (block-uniform), -1 for a workgroup in the padding between frames
+__device__ __forceinline__ int frame_of_slot(const BatchMap &B, int64_t s0)
+{
+    int f = -1;
+    for (int k = 0; k < B.n_frames; ++k)
+        if (B.count[k] > 0 && s0 >= B.base[k] && s0 < (int64_t)B.base[k] + B.count[k]) f = k;
+    return f;
+}
+
+__global__ __launch_bounds__(256) void frame_times_kernel(int64_t n_rays, int rays_per_frame,
+                                                          const float *__restrict__ frame_times, float *__restrict__ ts_ray)
+{
+    const int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (r < n_rays) ts_ray[r] = frame_times[r / rays_per_frame];
+}
 
 // Per-ray setup of cednerf/utils.py:197-225: zero the pixel accumulators, all rays alive, near
 // planes, ray/AABB intersection per grid level and the stably sorted entry/exit event list.
@@ -130,8 +160,8 @@ struct MarchArgs {
     GridSpec grid;
     float *near_planes;            // in: near plane, out: termination plane (cednerf/utils.py:301)
     float far_plane;
-    const int32_t *alive;          // ids of the rays still alive (NULL: all rays, first iteration)
-    int64_t n_alive;
+    const int32_t *alive;          // per-frame lists of the rays still alive (NULL: all rays, first iteration)
+    BatchMap map;
     const float *t_sorted;
     const int64_t *t_indices;
     const uint8_t *hits;
@@ -139,6 +169,7 @@ struct MarchArgs {
     int32_t *ray_idx;
     int32_t *packed;               // [n_rays, 2] (start, count)
     unsigned long long *counter;   // samples reserved so far in this iteration
+    unsigned long long *frame_samples;   // [n_frames] samples of each frame in this iteration
 };
 
 // Workgroup of T threads (T/64 waves).  Each ray marches once and stages its (t_start, t_end) pairs
@@ -152,11 +183,17 @@ __global__ __launch_bounds__(256) void march_alloc_kernel(MarchArgs A)
     __shared__ int wave_tot[16];
     __shared__ long long block_base;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, n_waves = blockDim.x >> 6;
-    const int limit = A.grid.limit;
+    const int64_t s0 = (int64_t)blockIdx.x * blockDim.x;
+    const int f = frame_of_slot(A.map, s0);
+    if (f < 0) return;                                   // padding between two frames' slot ranges (whole workgroup)
+    const int limit = A.map.limit[f];
     float2 *stage = stage_all + (size_t)wave * limit * 64;
-    const int64_t slot = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    const bool active = slot < A.n_alive;
-    const int64_t r = active ? (A.alive ? (int64_t)A.alive[slot] : slot) : 0;
+    const int64_t idx = s0 + threadIdx.x - A.map.base[f];
+    const bool active = idx < A.map.count[f];
+    const int64_t first = (int64_t)f * A.map.rays_per_frame;
+    const int64_t r = active ? (A.alive ? (int64_t)A.alive[first + idx] : first + idx) : 0;
+    GridSpec grid = A.grid;
+    grid.limit = limit;
     int n = 0;
 #ifdef CED_MARCH_PROFILE
     unsigned long long mp_acc[8] = { 0, 0, 0, 0, 0, 0, 0, 0 };
@@ -165,10 +202,10 @@ __global__ __launch_bounds__(256) void march_alloc_kernel(MarchArgs A)
     if (active) {
         const float o[3] = { A.rays_o[3 * r], A.rays_o[3 * r + 1], A.rays_o[3 * r + 2] };
         const float d[3] = { A.rays_d[3 * r], A.rays_d[3 * r + 1], A.rays_d[3 * r + 2] };
-        const int m = A.grid.n_grids;
+        const int m = grid.n_grids;
         float t_term;
         n = traverse_ray(
-            A.grid, o, d, A.near_planes[r], A.far_plane, A.t_sorted + r * 2 * m, A.t_indices + r * 2 * m,
+            grid, o, d, A.near_planes[r], A.far_plane, A.t_sorted + r * 2 * m, A.t_indices + r * 2 * m,
             A.hits + r * m, [&](int i, float t0, float t1) { stage[i * 64 + lane] = make_float2(t0, t1); }, t_term
 #ifdef CED_MARCH_PROFILE
             , mp_acc, mp_t
@@ -189,6 +226,7 @@ __global__ __launch_bounds__(256) void march_alloc_kernel(MarchArgs A)
         int run = 0;
         for (int w = 0; w < n_waves; ++w) { int t = wave_tot[w]; wave_tot[w] = run; run += t; }
         block_base = run > 0 ? (long long)atomicAdd(A.counter, (unsigned long long)run) : 0;
+        if (run > 0) atomicAdd(A.frame_samples + f, (unsigned long long)run);
     }
     __syncthreads();
     const int64_t start = (int64_t)block_base + wave_tot[wave] + (incl - n);
@@ -223,7 +261,7 @@ extern "C" int ced_debug_march_profile(unsigned long long *out16, int reset)
 // composite_prefix (cednerf/utils.py:274-299) + ray bookkeeping (utils.py:301-307) over the list of
 // alive rays; survivors (opacity <= threshold and a full sample budget) are appended to the next
 // iteration's list, one range reservation per workgroup.
-__global__ __launch_bounds__(256) void frame_composite_kernel(int64_t n_alive, const int32_t *__restrict__ alive_list,
+__global__ __launch_bounds__(256) void frame_composite_kernel(BatchMap map, const int32_t *__restrict__ alive_list,
                                                               int32_t *__restrict__ next_list,
                                                               unsigned long long *__restrict__ next_count,
                                                               const int32_t *__restrict__ packed,
@@ -232,13 +270,18 @@ __global__ __launch_bounds__(256) void frame_composite_kernel(int64_t n_alive, c
                                                               const float *__restrict__ sig,
                                                               const float *__restrict__ rgbs, float *__restrict__ rgb,
                                                               float *__restrict__ opacity, float *__restrict__ depth,
-                                                              float opc_thres, int n_samples_iter)
+                                                              float opc_thres)
 {
     __shared__ int wave_alive[4];
     __shared__ long long block_base;
-    const int64_t slot = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    const bool active = slot < n_alive;
-    const int64_t r = active ? (alive_list ? (int64_t)alive_list[slot] : slot) : 0;
+    const int64_t s0 = (int64_t)blockIdx.x * blockDim.x;
+    const int f = frame_of_slot(map, s0);
+    if (f < 0) return;                                   // padding between two frames' slot ranges (whole workgroup)
+    const int n_samples_iter = map.limit[f];
+    const int64_t idx = s0 + threadIdx.x - map.base[f];
+    const bool active = idx < map.count[f];
+    const int64_t first = (int64_t)f * map.rays_per_frame;
+    const int64_t r = active ? (alive_list ? (int64_t)alive_list[first + idx] : first + idx) : 0;
     int cnt = 0;
     bool alive = false;
     if (active) {
@@ -292,7 +335,7 @@ __global__ __launch_bounds__(256) void frame_composite_kernel(int64_t n_alive, c
             opacity[r] = op;
             depth[r] = dp;
         }
-        alive = (op <= opc_thres) && (cnt == n_samples_iter);
+        alive = !map.last[f] && (op <= opc_thres) && (cnt == n_samples_iter);
     }
     const unsigned long long ballot = __ballot(alive);
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -301,12 +344,12 @@ __global__ __launch_bounds__(256) void frame_composite_kernel(int64_t n_alive, c
     if (threadIdx.x == 0) {
         int run = 0;
         for (int w = 0; w < 4; ++w) { int t = wave_alive[w]; wave_alive[w] = run; run += t; }
-        block_base = run > 0 ? (long long)atomicAdd(next_count, (unsigned long long)run) : 0;
+        block_base = run > 0 ? (long long)atomicAdd(next_count + f, (unsigned long long)run) : 0;
     }
     __syncthreads();
     if (alive) {
         const int rank = __builtin_popcountll(ballot & ((1ull << lane) - 1ull));
-        next_list[block_base + wave_alive[wave] + rank] = (int32_t)r;
+        next_list[first + block_base + wave_alive[wave] + rank] = (int32_t)r;
     }
 }
 
@@ -328,10 +371,21 @@ __global__ __launch_bounds__(256) void frame_finalize_kernel(int64_t n_rays, con
 
 // Hands the iteration's two counters to the host through mapped pinned memory and raises a sequence
 // number; the host spins on it instead of paying a copy + hipStreamSynchronize round trip.
-__global__ void frame_publish_kernel(const unsigned long long *__restrict__ counters, long long *host, long long seq)
+__global__ void frame_publish_kernel(const unsigned long long *__restrict__ it_counters,
+                                     const unsigned long long *__restrict__ next_counters, int n_frames, long long *host,
+                                     long long seq)
 {
-    host[0] = (long long)counters[0];       // samples reserved in this iteration
-    host[1] = (long long)counters[3];       // rays alive entering the next iteration
+    // per-iteration counter block: [0] samples reserved, [2+f] rays of frame f alive entering the iteration,
+    // [2+F+f] samples of frame f
+    long long alive_next = 0;
+    for (int f = 0; f < n_frames; ++f) alive_next += (long long)next_counters[2 + f];
+    host[0] = (long long)it_counters[0];    // samples reserved in this iteration
+    host[1] = alive_next;                   // rays alive entering the next iteration
+    if (n_frames > 1)
+        for (int f = 0; f < n_frames; ++f) {
+            host[3 + f] = (long long)next_counters[2 + f];
+            host[3 + n_frames + f] = (long long)it_counters[2 + n_frames + f];
+        }
     __threadfence_system();
     __hip_atomic_store(&host[2], seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
 }
@@ -341,13 +395,15 @@ static inline size_t align_up(size_t x) { return (x + 255) & ~(size_t)255; }
 struct FrameWorkspace {
     float *t_sorted; int64_t *t_indices; uint8_t *hits; float *near; int32_t *packed;
     int32_t *alive_a, *alive_b;     // double-buffered list of alive ray ids
-    unsigned long long *counters;   // [iters+2][2]: {samples reserved in iteration i, rays alive entering iteration i}
+    unsigned long long *counters;   // [iters+2][2+2F]: see frame_publish_kernel
+    float *ts_ray;                  // per-ray time of a multi-frame call
     float *t0, *t1; int32_t *ridx; float *sigma, *rgbs;
     uint8_t *brick_any, *brick_dil;
     size_t bytes;
 };
 
-static FrameWorkspace carve(void *base, int64_t n, int m, int64_t cap, int max_iters, int res)
+static FrameWorkspace carve(void *base, int64_t n, int m, int64_t cap, int max_iters, int res, int n_frames = 1,
+                            bool per_ray_times = false)
 {
     FrameWorkspace w{};
     size_t off = 0;
@@ -359,7 +415,8 @@ static FrameWorkspace carve(void *base, int64_t n, int m, int64_t cap, int max_i
     w.packed = (int32_t *)take((size_t)n * 8);
     w.alive_a = (int32_t *)take((size_t)n * 4);
     w.alive_b = (int32_t *)take((size_t)n * 4);
-    w.counters = (unsigned long long *)take((size_t)(max_iters + 2) * 16);
+    w.counters = (unsigned long long *)take((size_t)(max_iters + 2) * (2 + 2 * n_frames) * 8);
+    w.ts_ray = (float *)take(per_ray_times ? (size_t)n * 4 : 0);
     w.t0 = (float *)take((size_t)cap * 4);
     w.t1 = (float *)take((size_t)cap * 4);
     w.ridx = (int32_t *)take((size_t)cap * 4);
@@ -375,6 +432,194 @@ static FrameWorkspace carve(void *base, int64_t n, int m, int64_t cap, int max_i
 static std::atomic<long long> g_publish_seq{ 0 };
 
 static inline int min_samples_of(float cone_angle) { return cone_angle == 0.0f ? 1 : 4; }
+
+// The frame loop for `n_frames` frames of `rays_per_frame` rays each (ced_render_image_test: one frame).
+// frame_times == nullptr: `timestamps` is what the field kernel gets ([1] shared or [n_rays] per ray, t_per_ray);
+// otherwise frame_times [n_frames] holds one time per frame and is expanded to a per-ray array.
+static int render_frames_impl(const ced_field_desc *field, int n_frames, int64_t rays_per_frame, const float *rays_o,
+                              const float *rays_d, const uint8_t *binaries, int32_t n_grids, int32_t res,
+                              const float *aabbs, float near_plane, float far_plane, float step_size, float cone_angle,
+                              float early_stop_eps, int32_t max_samples, const float *timestamps, int32_t t_per_ray,
+                              const float *frame_times, const float *bkgd, float *rgb, float *opacity, float *depth,
+                              void *workspace, int64_t workspace_bytes, int64_t *host_stats, int64_t *total_samples_out,
+                              ced_frame_trace *trace, void *field_stream_, void *stream_, const char *who)
+{
+    hipStream_t stream = (hipStream_t)stream_;
+    // Optional separate stream for the field kernel: callers that keep several frames in flight hand
+    // every frame the same field stream, so the MFMA-bound field launches of different frames queue
+    // behind each other (overlapping them buys nothing) while the latency-bound marching / compositing
+    // launches and the host hand-shake of one frame run beside the field kernel of another.
+    hipStream_t fstream = field_stream_ ? (hipStream_t)field_stream_ : stream;
+    const bool split = fstream != stream;
+    static thread_local hipEvent_t ev_to_field = nullptr, ev_from_field = nullptr;
+    if (split && !ev_to_field) {
+        if (hipEventCreateWithFlags(&ev_to_field, hipEventDisableTiming) != hipSuccess ||
+            hipEventCreateWithFlags(&ev_from_field, hipEventDisableTiming) != hipSuccess)
+            return check_launch("render_image_test (event create)");
+    }
+    const int64_t n_rays = (int64_t)n_frames * rays_per_frame;
+    CED_REQUIRE(field != nullptr, "%s: null field descriptor", who);
+    CED_REQUIRE(n_frames >= 1 && n_frames <= kMaxFrames, "%s: n_frames must be 1..%d", who, kMaxFrames);
+    CED_REQUIRE(rays_per_frame >= 0 && n_grids >= 1 && n_grids <= kMaxGrids && res >= 1 && res <= 1024, "%s: bad sizes", who);
+    CED_REQUIRE(n_rays < (1ll << 31) / 4, "%s: too many rays for 32-bit sample indices", who);
+    CED_REQUIRE(max_samples >= 0, "%s: max_samples < 0", who);
+    if (total_samples_out)
+        for (int f = 0; f < n_frames; ++f) total_samples_out[f] = 0;
+    if (trace) trace->n_iters = 0;
+    if (n_rays == 0) return CED_OK;
+    CED_REQUIRE(rays_o && rays_d && binaries && aabbs && (timestamps || frame_times) && rgb && opacity && depth &&
+                    workspace && host_stats,
+                "%s: null pointer", who);
+    const int min_samples = min_samples_of(cone_angle);
+    const int64_t cap = n_rays * min_samples;
+    FrameWorkspace W = carve(workspace, n_rays, n_grids, cap, max_samples + 1, res, n_frames, frame_times != nullptr);
+    CED_REQUIRE((int64_t)W.bytes <= workspace_bytes, "%s: workspace too small (%lld < %lld bytes)", who,
+                (long long)workspace_bytes, (long long)W.bytes);
+    const dim3 blk(256), grd((unsigned)((n_rays + 255) / 256));
+    static bool lds_attr_set = false;
+    if (!lds_attr_set) {        // the marching kernel stages up to 128 KB of samples per workgroup
+        if (hipFuncSetAttribute(reinterpret_cast<const void *>(march_alloc_kernel),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024) != hipSuccess)
+            return check_launch("render_image_test (LDS attribute)");
+        lds_attr_set = true;
+    }
+
+    hipLaunchKernelGGL(frame_prep_kernel, grd, blk, 0, stream, n_rays, rays_o, rays_d, (int)n_grids, aabbs, near_plane,
+                       W.t_sorted, W.t_indices, W.hits, W.near, rgb, opacity, depth);
+    if (frame_times)
+        hipLaunchKernelGGL(frame_times_kernel, grd, blk, 0, stream, n_rays, (int)rays_per_frame, frame_times, W.ts_ray);
+    const size_t cstride = 2 + 2 * (size_t)n_frames;              // counters per iteration (see frame_publish_kernel)
+    if (hipMemsetAsync(W.counters, 0, (size_t)(max_samples + 3) * cstride * 8, stream) != hipSuccess)
+        return check_launch("render_image_test (memset)");
+    const int nb = (res + kBrick - 1) / kBrick;
+    const int n_bricks = n_grids * nb * nb * nb;
+    hipLaunchKernelGGL(brick_any_kernel, dim3(n_bricks), dim3(64), 0, stream, binaries, (int)n_grids, (int)res, nb,
+                       W.brick_any);
+    hipLaunchKernelGGL(brick_dilate_kernel, dim3((n_bricks + 255) / 256), blk, 0, stream, W.brick_any, (int)n_grids, nb,
+                       W.brick_dil);
+    int rc = check_launch("render_image_test (prep)");
+    if (rc) return rc;
+
+    const float opc_thres = (float)(1.0 - (double)early_stop_eps);
+    int64_t alive[kMaxFrames], total[kMaxFrames];
+    int iter_samples[kMaxFrames];
+    for (int f = 0; f < n_frames; ++f) { alive[f] = rays_per_frame; total[f] = 0; iter_samples[f] = 0; }
+    int it = 0;
+    for (;;) {
+        // every frame advances its own reference loop (cednerf/utils.py:227-238): while iteration < max_samples and
+        // rays are alive, N_samples = clamp(N_rays // N_alive, min, 64), iteration += N_samples
+        BatchMap B{};
+        B.n_frames = n_frames;
+        B.rays_per_frame = (int)rays_per_frame;
+        int64_t slots = 0, upper = 0, alive_total = 0;
+        int max_limit = 0;
+        for (int f = 0; f < n_frames; ++f) {
+            if (alive[f] <= 0 || iter_samples[f] >= max_samples) continue;
+            const int64_t q = rays_per_frame / alive[f];
+            int n_samples = (int)(q < 64 ? q : 64);
+            if (n_samples < min_samples) n_samples = min_samples;
+            iter_samples[f] += n_samples;
+            B.base[f] = (int)slots;
+            B.count[f] = (int)alive[f];
+            B.limit[f] = n_samples;
+            B.last[f] = iter_samples[f] >= max_samples ? 1 : 0;
+            slots = (slots + alive[f] + 255) & ~(int64_t)255;
+            upper += alive[f] * n_samples;
+            alive_total += alive[f];
+            if (n_samples > max_limit) max_limit = n_samples;
+        }
+        if (alive_total == 0) break;
+        unsigned long long *it_counters = W.counters + (size_t)it * cstride;
+        unsigned long long *next_counters = W.counters + (size_t)(it + 1) * cstride;
+        unsigned long long *counter = it_counters;                                  // samples reserved in this iteration
+        const int32_t *cur_list = it == 0 ? nullptr : ((it & 1) ? W.alive_a : W.alive_b);
+        int32_t *next_list = (it & 1) ? W.alive_b : W.alive_a;
+
+        MarchArgs M{ n_rays, rays_o, rays_d,
+                     GridSpec{ binaries, aabbs, n_grids, res, step_size, cone_angle, max_limit,
+                               g_march_early_out ? W.brick_dil : nullptr, nb, it > 0 ? 1 : 0 },
+                     W.near, far_plane, cur_list, B, W.t_sorted, W.t_indices, W.hits, W.t0, W.t1, W.ridx, W.packed,
+                     counter, it_counters + 2 + n_frames };
+        // only alive rays get a lane; 128 rays per workgroup (CED_MARCH_THREADS): a workgroup lives as long as its
+        // slowest ray (its waves meet at the range reservation), while one reservation still serves 128 rays
+        static const int threads_env = [] {
+            const char *e = getenv("CED_MARCH_THREADS");
+            const int t = e ? atoi(e) : 128;
+            return (t == 64 || t == 128 || t == 256) ? t : 128;
+        }();
+        const int threads = threads_env;
+        hipLaunchKernelGGL(march_alloc_kernel, dim3((unsigned)(slots / threads)), dim3(threads),
+                           (size_t)threads * max_limit * sizeof(float2), stream, M);
+        rc = check_launch("render_image_test (march)");
+        if (rc) return rc;
+
+        FieldArgs F{};
+        F.n = upper;                        // host-side upper bound; the kernel reads the exact count
+        F.n_dev = reinterpret_cast<const int64_t *>(counter);
+        F.rays_o = rays_o; F.rays_d = rays_d; F.ray_idx32 = W.ridx;
+        F.t0 = W.t0; F.t1 = W.t1;
+        F.timestamps = frame_times ? W.ts_ray : timestamps;
+        F.rays_mode = 1; F.t_per_ray = (frame_times || t_per_ray) ? 1 : 0; F.want_rgb = 1;
+        F.rgb = W.rgbs; F.sigma = W.sigma; F.geo = nullptr;
+        if (split) {
+            (void)hipEventRecord(ev_to_field, stream);
+            (void)hipStreamWaitEvent(fstream, ev_to_field, 0);
+        }
+        if (trace && it < trace->capacity && trace->field_begin)
+            (void)hipEventRecord((hipEvent_t)trace->field_begin[it], fstream);
+        rc = launch_field(field, F, (void *)fstream);
+        if (rc) return rc;
+        if (trace && it < trace->capacity && trace->field_end)
+            (void)hipEventRecord((hipEvent_t)trace->field_end[it], fstream);
+        if (split) {
+            (void)hipEventRecord(ev_from_field, fstream);
+            (void)hipStreamWaitEvent(stream, ev_from_field, 0);
+        }
+
+        hipLaunchKernelGGL(frame_composite_kernel, dim3((unsigned)(slots / 256)), blk, 0, stream, B, cur_list, next_list,
+                           next_counters + 2, W.packed, W.t0, W.t1, W.sigma, W.rgbs, rgb, opacity, depth, opc_thres);
+        rc = check_launch("render_image_test (composite)");
+        if (rc) return rc;
+        // {samples of this iteration, rays alive for the next} -> pinned host memory; spin on the sequence
+        // number (falls back to a stream synchronise if the flag does not show up)
+        const long long seq = ++g_publish_seq;
+        hipLaunchKernelGGL(frame_publish_kernel, dim3(1), dim3(1), 0, stream, it_counters, next_counters, n_frames,
+                           (long long *)host_stats, seq);
+        rc = check_launch("render_image_test (publish)");
+        if (rc) return rc;
+        {
+            volatile long long *flag = (volatile long long *)host_stats + 2;
+            const auto t_start = std::chrono::steady_clock::now();
+            long spins = 0;
+            while (__atomic_load_n(flag, __ATOMIC_ACQUIRE) != seq) {
+                if ((++spins & 0xfff) == 0 &&
+                    std::chrono::steady_clock::now() - t_start > std::chrono::milliseconds(200)) {
+                    if (hipStreamSynchronize(stream) != hipSuccess) return check_launch("render_image_test (sync)");
+                    break;
+                }
+            }
+        }
+        const int64_t samples_it = host_stats[0];
+        if (trace && it < trace->capacity) {
+            if (trace->iter_alive) trace->iter_alive[it] = alive_total;
+            if (trace->iter_n_samples) trace->iter_n_samples[it] = max_limit;
+            if (trace->iter_samples) trace->iter_samples[it] = samples_it;
+        }
+        for (int f = 0; f < n_frames; ++f) {
+            if (B.count[f] == 0) continue;
+            alive[f] = n_frames > 1 ? host_stats[3 + f] : host_stats[1];
+            total[f] += n_frames > 1 ? host_stats[3 + n_frames + f] : samples_it;
+        }
+        ++it;
+    }
+    if (trace) trace->n_iters = it;
+    hipLaunchKernelGGL(frame_finalize_kernel, grd, blk, 0, stream, n_rays, bkgd, rgb, opacity, depth);
+    rc = check_launch("render_image_test (finalize)");
+    if (rc) return rc;
+    if (total_samples_out)
+        for (int f = 0; f < n_frames; ++f) total_samples_out[f] = total[f];
+    return CED_OK;
+}
 
 }  // namespace ced
 
@@ -395,143 +640,35 @@ extern "C" int ced_render_image_test(const ced_field_desc *field, int64_t n_rays
                                      int64_t *host_stats, int64_t *total_samples_out, ced_frame_trace *trace,
                                      void *field_stream_, void *stream_)
 {
-    using namespace ced;
-    hipStream_t stream = (hipStream_t)stream_;
-    // Optional separate stream for the field kernel: callers that keep several frames in flight hand
-    // every frame the same field stream, so the MFMA-bound field launches of different frames queue
-    // behind each other (overlapping them buys nothing) while the latency-bound marching / compositing
-    // launches and the host hand-shake of one frame run beside the field kernel of another.
-    hipStream_t fstream = field_stream_ ? (hipStream_t)field_stream_ : stream;
-    const bool split = fstream != stream;
-    static thread_local hipEvent_t ev_to_field = nullptr, ev_from_field = nullptr;
-    if (split && !ev_to_field) {
-        if (hipEventCreateWithFlags(&ev_to_field, hipEventDisableTiming) != hipSuccess ||
-            hipEventCreateWithFlags(&ev_from_field, hipEventDisableTiming) != hipSuccess)
-            return check_launch("render_image_test (event create)");
-    }
-    CED_REQUIRE(field != nullptr, "render_image_test: null field descriptor");
-    CED_REQUIRE(n_rays >= 0 && n_grids >= 1 && n_grids <= kMaxGrids && res >= 1 && res <= 1024, "render_image_test: bad sizes");
-    CED_REQUIRE(n_rays < (1ll << 31) / 4, "render_image_test: too many rays for 32-bit sample indices");
-    CED_REQUIRE(max_samples >= 0, "render_image_test: max_samples < 0");
-    if (total_samples_out) *total_samples_out = 0;
-    if (trace) trace->n_iters = 0;
-    if (n_rays == 0) return CED_OK;
-    CED_REQUIRE(rays_o && rays_d && binaries && aabbs && timestamps && rgb && opacity && depth && workspace &&
-                    host_stats,
-                "render_image_test: null pointer");
-    const int min_samples = min_samples_of(cone_angle);
-    const int64_t cap = n_rays * min_samples;
-    FrameWorkspace W = carve(workspace, n_rays, n_grids, cap, max_samples + 1, res);
-    CED_REQUIRE((int64_t)W.bytes <= workspace_bytes, "render_image_test: workspace too small (%lld < %lld bytes)",
-                (long long)workspace_bytes, (long long)W.bytes);
-    const dim3 blk(256), grd((unsigned)((n_rays + 255) / 256));
-    static bool lds_attr_set = false;
-    if (!lds_attr_set) {        // the marching kernel stages up to 128 KB of samples per workgroup
-        if (hipFuncSetAttribute(reinterpret_cast<const void *>(march_alloc_kernel),
-                                hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024) != hipSuccess)
-            return check_launch("render_image_test (LDS attribute)");
-        lds_attr_set = true;
-    }
+    return ced::render_frames_impl(field, 1, n_rays, rays_o, rays_d, binaries, n_grids, res, aabbs, near_plane, far_plane,
+                                   step_size, cone_angle, early_stop_eps, max_samples, timestamps, t_per_ray, nullptr, bkgd,
+                                   rgb, opacity, depth, workspace, workspace_bytes, host_stats, total_samples_out, trace,
+                                   field_stream_, stream_, "render_image_test");
+}
 
-    hipLaunchKernelGGL(frame_prep_kernel, grd, blk, 0, stream, n_rays, rays_o, rays_d, (int)n_grids, aabbs, near_plane,
-                       W.t_sorted, W.t_indices, W.hits, W.near, rgb, opacity, depth);
-    if (hipMemsetAsync(W.counters, 0, (size_t)(max_samples + 3) * 16, stream) != hipSuccess)
-        return check_launch("render_image_test (memset)");
-    const int nb = (res + kBrick - 1) / kBrick;
-    const int n_bricks = n_grids * nb * nb * nb;
-    hipLaunchKernelGGL(brick_any_kernel, dim3(n_bricks), dim3(64), 0, stream, binaries, (int)n_grids, (int)res, nb,
-                       W.brick_any);
-    hipLaunchKernelGGL(brick_dilate_kernel, dim3((n_bricks + 255) / 256), blk, 0, stream, W.brick_any, (int)n_grids, nb,
-                       W.brick_dil);
-    int rc = check_launch("render_image_test (prep)");
-    if (rc) return rc;
+extern "C" int64_t ced_render_frames_test_workspace_bytes(int32_t n_frames, int64_t rays_per_frame, int32_t n_grids,
+                                                          int32_t res, float cone_angle, int32_t max_samples)
+{
+    if (n_frames < 1 || n_frames > ced::kMaxFrames || rays_per_frame < 0 || n_grids < 1 || n_grids > ced::kMaxGrids ||
+        res < 1 || res > 1024 || max_samples < 0)
+        return -1;
+    const int64_t n_rays = (int64_t)n_frames * rays_per_frame;
+    const int64_t cap = n_rays * ced::min_samples_of(cone_angle);
+    return (int64_t)ced::carve(nullptr, n_rays, n_grids, cap, max_samples + 1, res, n_frames, true).bytes;
+}
 
-    const float opc_thres = (float)(1.0 - (double)early_stop_eps);
-    int64_t n_alive = n_rays, total = 0;
-    int iter_samples = 0, it = 0;
-    while (iter_samples < max_samples && n_alive > 0) {
-        int64_t q = n_rays / n_alive;
-        int n_samples = (int)(q < 64 ? q : 64);
-        if (n_samples < min_samples) n_samples = min_samples;
-        iter_samples += n_samples;
-        unsigned long long *counter = W.counters + (size_t)it * 2;          // samples reserved in this iteration
-        unsigned long long *next_alive = W.counters + (size_t)(it + 1) * 2 + 1;   // rays alive entering the next one
-        const int32_t *cur_list = it == 0 ? nullptr : ((it & 1) ? W.alive_a : W.alive_b);
-        int32_t *next_list = (it & 1) ? W.alive_b : W.alive_a;
-
-        MarchArgs M{ n_rays, rays_o, rays_d,
-                     GridSpec{ binaries, aabbs, n_grids, res, step_size, cone_angle, n_samples,
-                               g_march_early_out ? W.brick_dil : nullptr, nb, it > 0 ? 1 : 0 },
-                     W.near, far_plane, cur_list, n_alive, W.t_sorted, W.t_indices, W.hits, W.t0, W.t1, W.ridx, W.packed,
-                     counter };
-        // only alive rays get a lane; 128 rays per workgroup (CED_MARCH_THREADS): a workgroup lives as long as its
-        // slowest ray (its waves meet at the range reservation), while one reservation still serves 128 rays
-        static const int threads_env = [] { const char *e = getenv("CED_MARCH_THREADS"); return e ? atoi(e) : 128; }();
-        const int threads = threads_env;
-        hipLaunchKernelGGL(march_alloc_kernel, dim3((unsigned)((n_alive + threads - 1) / threads)), dim3(threads),
-                           (size_t)threads * n_samples * sizeof(float2), stream, M);
-        rc = check_launch("render_image_test (march)");
-        if (rc) return rc;
-
-        FieldArgs F{};
-        F.n = n_alive * n_samples;          // host-side upper bound; the kernel reads the exact count
-        F.n_dev = reinterpret_cast<const int64_t *>(counter);
-        F.rays_o = rays_o; F.rays_d = rays_d; F.ray_idx32 = W.ridx;
-        F.t0 = W.t0; F.t1 = W.t1; F.timestamps = timestamps;
-        F.rays_mode = 1; F.t_per_ray = t_per_ray ? 1 : 0; F.want_rgb = 1;
-        F.rgb = W.rgbs; F.sigma = W.sigma; F.geo = nullptr;
-        if (split) {
-            (void)hipEventRecord(ev_to_field, stream);
-            (void)hipStreamWaitEvent(fstream, ev_to_field, 0);
-        }
-        if (trace && it < trace->capacity && trace->field_begin)
-            (void)hipEventRecord((hipEvent_t)trace->field_begin[it], fstream);
-        rc = launch_field(field, F, (void *)fstream);
-        if (rc) return rc;
-        if (trace && it < trace->capacity && trace->field_end)
-            (void)hipEventRecord((hipEvent_t)trace->field_end[it], fstream);
-        if (split) {
-            (void)hipEventRecord(ev_from_field, fstream);
-            (void)hipStreamWaitEvent(stream, ev_from_field, 0);
-        }
-
-        hipLaunchKernelGGL(frame_composite_kernel, dim3((unsigned)((n_alive + 255) / 256)), blk, 0, stream, n_alive,
-                           cur_list, next_list, next_alive, W.packed, W.t0, W.t1, W.sigma, W.rgbs, rgb, opacity, depth,
-                           opc_thres, n_samples);
-        rc = check_launch("render_image_test (composite)");
-        if (rc) return rc;
-        // {samples of this iteration, rays alive for the next} -> pinned host memory; spin on the sequence
-        // number (falls back to a stream synchronise if the flag does not show up)
-        const long long seq = ++g_publish_seq;
-        hipLaunchKernelGGL(frame_publish_kernel, dim3(1), dim3(1), 0, stream, counter, (long long *)host_stats, seq);
-        rc = check_launch("render_image_test (publish)");
-        if (rc) return rc;
-        {
-            volatile long long *flag = (volatile long long *)host_stats + 2;
-            const auto t_start = std::chrono::steady_clock::now();
-            long spins = 0;
-            while (__atomic_load_n(flag, __ATOMIC_ACQUIRE) != seq) {
-                if ((++spins & 0xfff) == 0 &&
-                    std::chrono::steady_clock::now() - t_start > std::chrono::milliseconds(200)) {
-                    if (hipStreamSynchronize(stream) != hipSuccess) return check_launch("render_image_test (sync)");
-                    break;
-                }
-            }
-        }
-        const int64_t samples_it = host_stats[0], alive_next = host_stats[1];
-        if (trace && it < trace->capacity) {
-            if (trace->iter_alive) trace->iter_alive[it] = n_alive;
-            if (trace->iter_n_samples) trace->iter_n_samples[it] = n_samples;
-            if (trace->iter_samples) trace->iter_samples[it] = samples_it;
-        }
-        n_alive = alive_next;
-        total += samples_it;
-        ++it;
-    }
-    if (trace) trace->n_iters = it;
-    hipLaunchKernelGGL(frame_finalize_kernel, grd, blk, 0, stream, n_rays, bkgd, rgb, opacity, depth);
-    rc = check_launch("render_image_test (finalize)");
-    if (rc) return rc;
-    if (total_samples_out) *total_samples_out = total;
-    return CED_OK;
+extern "C" int ced_render_frames_test(const ced_field_desc *field, int32_t n_frames, int64_t rays_per_frame,
+                                      const float *rays_o, const float *rays_d, const uint8_t *binaries, int32_t n_grids,
+                                      int32_t res, const float *aabbs, float near_plane, float far_plane, float step_size,
+                                      float cone_angle, float early_stop_eps, int32_t max_samples,
+                                      const float *frame_times, const float *bkgd, float *rgb, float *opacity,
+                                      float *depth, void *workspace, int64_t workspace_bytes, int64_t *host_stats,
+                                      int64_t *total_samples_out, ced_frame_trace *trace, void *field_stream_,
+                                      void *stream_)
+{
+    CED_REQUIRE(frame_times != nullptr, "render_frames_test: null frame_times");
+    return ced::render_frames_impl(field, n_frames, rays_per_frame, rays_o, rays_d, binaries, n_grids, res, aabbs,
+                                   near_plane, far_plane, step_size, cone_angle, early_stop_eps, max_samples, nullptr, 0,
+                                   frame_times, bkgd, rgb, opacity, depth, workspace, workspace_bytes, host_stats,
+                                   total_samples_out, trace, field_stream_, stream_, "render_frames_test");
 }

@@ -427,7 +427,7 @@ def render_image_test_native(desc: _lib.FieldDesc, rays_o, rays_d, binaries, aab
         ws = _frame_ws.get(key)
         if ws is None or ws[0].numel() < need:
             ws = (torch.empty((max(need, 1),), device=dev, dtype=torch.uint8),
-                  torch.zeros((8,), dtype=torch.int64).pin_memory())
+                  ws[1] if ws is not None else torch.zeros((32,), dtype=torch.int64).pin_memory())
             _frame_ws[key] = ws
     rgb = torch.empty((n, 3), device=dev, dtype=torch.float32)
     opacity = torch.empty((n, 1), device=dev, dtype=torch.float32)
@@ -441,6 +441,47 @@ def render_image_test_native(desc: _lib.FieldDesc, rays_o, rays_d, binaries, aab
                                  C.c_void_p(field_stream.cuda_stream) if field_stream is not None else None, _stream())
     _lib.check(rc, "render_image_test")
     return rgb, opacity, depth, int(total.value)
+
+
+def render_frames_test_native(desc: _lib.FieldDesc, n_frames: int, rays_o, rays_d, binaries, aabbs, near_plane, far_plane,
+                              render_step_size, cone_angle, early_stop_eps, max_samples, frame_times, bkgd,
+                              tracer: Optional[FrameTracer] = None, field_stream: Optional[torch.cuda.Stream] = None):
+    """ced_render_frames_test: `n_frames` frames (rays frame-major, [n_frames * rays_per_frame, 3]) through shared
+    launches, every frame on its own schedule.  Returns (rgb [N,3], opacity [N,1], depth [N,1], [total_samples per frame])."""
+    _chk(rays_o, torch.float32, "rays_o"); _chk(rays_d, torch.float32, "rays_d")
+    _chk(aabbs, torch.float32, "aabbs"); _chk(frame_times, torch.float32, "frame_times")
+    _chk(bkgd, torch.float32, "render_bkgd", allow_none=True)
+    assert rays_o.ndim == 2 and rays_o.shape[1] == 3 and rays_o.shape == rays_d.shape
+    assert binaries.is_cuda and binaries.is_contiguous() and binaries.ndim == 4
+    n = rays_o.shape[0]
+    assert n_frames >= 1 and n % n_frames == 0, "rays must hold n_frames equal frames"
+    assert frame_times.numel() == n_frames, "one time per frame"
+    m, res = binaries.shape[0], binaries.shape[1]
+    assert aabbs.shape == (m, 6)
+    dev = rays_o.device
+    L = _lib.lib()
+    need = int(L.ced_render_frames_test_workspace_bytes(n_frames, n // n_frames, m, res, float(cone_angle), int(max_samples)))
+    if need < 0:
+        raise ValueError("render_frames_test: unsupported sizes (1..8 frames)")
+    key = (dev.index, torch.cuda.current_stream().cuda_stream)
+    with _frame_ws_lock:
+        ws = _frame_ws.get(key)
+        if ws is None or ws[0].numel() < need:
+            ws = (torch.empty((max(need, 1),), device=dev, dtype=torch.uint8),
+                  ws[1] if ws is not None else torch.zeros((32,), dtype=torch.int64).pin_memory())
+            _frame_ws[key] = ws
+    rgb = torch.empty((n, 3), device=dev, dtype=torch.float32)
+    opacity = torch.empty((n, 1), device=dev, dtype=torch.float32)
+    depth = torch.empty((n, 1), device=dev, dtype=torch.float32)
+    totals = (C.c_int64 * n_frames)()
+    rc = L.ced_render_frames_test(C.byref(desc), n_frames, n // n_frames, _p(rays_o), _p(rays_d), _p(_as_u8(binaries)), m,
+                                  res, _p(aabbs), float(near_plane), float(far_plane), float(render_step_size),
+                                  float(cone_angle), float(early_stop_eps), int(max_samples), _p(frame_times), _p(bkgd),
+                                  _p(rgb), _p(opacity), _p(depth), _p(ws[0]), ws[0].numel(), C.c_void_p(ws[1].data_ptr()),
+                                  totals, C.byref(tracer.struct) if tracer is not None else None,
+                                  C.c_void_p(field_stream.cuda_stream) if field_stream is not None else None, _stream())
+    _lib.check(rc, "render_frames_test")
+    return rgb, opacity, depth, [int(v) for v in totals]
 
 
 # ----------------------------------------------------------------------------------------------

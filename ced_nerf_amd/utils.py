@@ -162,6 +162,47 @@ def render_image_test(
 
 
 @torch.no_grad()
+def render_frames_test(
+    max_samples: int,
+    radiance_field: torch.nn.Module,
+    estimator: OccGridEstimator,
+    rays: Rays,
+    near_plane: float = 0.0,
+    far_plane: float = 1e10,
+    render_step_size: float = 1e-3,
+    render_bkgd: Optional[torch.Tensor] = None,
+    cone_angle: float = 0.0,
+    alpha_thre: float = 0.0,
+    early_stop_eps: float = 1e-4,
+    timestamps: Optional[torch.Tensor] = None,
+    tracer=None,
+    field_stream=None,
+):
+    """`render_image_test` for a stack of frames in one native call (ced_render_frames_test): rays.origins / viewdirs
+    are [F, ..., 3] (F <= 8 frames of equal size), timestamps holds F times.  The frames share the launches of an
+    iteration but each keeps its own reference loop, so frame f of the result equals
+    `render_image_test(rays[f], timestamps[f])` bit for bit.  Returns (rgb [F,...,3], opacity [F,...,1],
+    depth [F,...,1], [total_samples of every frame])."""
+    if timestamps is None:
+        raise NotImplementedError("DNGPradianceField needs timestamps (dnerf path of cednerf/utils.py:186-194)")
+    if radiance_field.training:
+        raise NotImplementedError("render_frames_test renders eval frames (one time per frame)")
+    shape = tuple(rays.origins.shape)
+    assert len(shape) >= 3 and shape[-1] == 3 and tuple(rays.viewdirs.shape) == shape, "rays must be [F, ..., 3]"
+    n_frames = shape[0]
+    rays_o = rays.origins.reshape(-1, 3).contiguous().float()
+    rays_d = rays.viewdirs.reshape(-1, 3).contiguous().float()
+    bk = None if render_bkgd is None else render_bkgd.to(rays_o.device, torch.float32).reshape(-1).contiguous()
+    ts = timestamps.reshape(-1).float().contiguous()
+    assert ts.numel() == n_frames, "one timestamp per frame"
+    rgb, opacity, depth, totals = ops.render_frames_test_native(
+        radiance_field._descriptor(), n_frames, rays_o, rays_d, estimator.binaries, estimator.aabbs.contiguous(),
+        near_plane, far_plane, render_step_size, cone_angle, early_stop_eps, max_samples, ts, bk,
+        tracer=tracer, field_stream=field_stream)
+    return rgb.view((*shape[:-1], 3)), opacity.view((*shape[:-1], 1)), depth.view((*shape[:-1], 1)), totals
+
+
+@torch.no_grad()
 def render_image_test_staged(
     max_samples: int,
     radiance_field: torch.nn.Module,

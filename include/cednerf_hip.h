@@ -340,6 +340,27 @@ int ced_render_image_test(const ced_field_desc *field, int64_t n_rays, const flo
                           void *workspace, int64_t workspace_bytes, int64_t *host_stats,
                           int64_t *total_samples_out, ced_frame_trace *trace, void *field_stream, void *stream);
 
+/* Several frames of a video in ONE call: the reference renders them one after another with
+ * render_image_test (train_real.py:531-558); here `n_frames` (1..8) frames of `rays_per_frame` rays each share the
+ * launches of an iteration -- one marching, one field and one compositing launch cover the alive rays of all the
+ * frames -- while EVERY FRAME KEEPS ITS OWN reference loop: N_samples = clamp(N_rays // N_alive, min, 64) on its own
+ * counts, its own `iteration < max_samples` end.  Each frame's pixels and sample count are therefore exactly those of
+ * ced_render_image_test on that frame alone; what changes is that the field launches are n_frames times larger
+ * (a launch's start-up and tail cost as much as ~40 us of its ~250 us at 800x800).
+ *   rays_o, rays_d [n_frames * rays_per_frame, 3] (frame-major); frame_times: device [n_frames], one time per frame;
+ *   outputs rgb [n_frames * rays_per_frame, 3], opacity, depth; workspace of
+ *   ced_render_frames_test_workspace_bytes() bytes; host_stats: PINNED host memory, >= 256 bytes;
+ *   total_samples_out: host [n_frames].  Everything else as ced_render_image_test. */
+int64_t ced_render_frames_test_workspace_bytes(int32_t n_frames, int64_t rays_per_frame, int32_t n_grids, int32_t res,
+                                               float cone_angle, int32_t max_samples);
+int ced_render_frames_test(const ced_field_desc *field, int32_t n_frames, int64_t rays_per_frame,
+                           const float *rays_o, const float *rays_d, const uint8_t *binaries, int32_t n_grids,
+                           int32_t res, const float *aabbs, float near_plane, float far_plane,
+                           float render_step_size, float cone_angle, float early_stop_eps, int32_t max_samples,
+                           const float *frame_times, const float *bkgd, float *rgb, float *opacity, float *depth,
+                           void *workspace, int64_t workspace_bytes, int64_t *host_stats,
+                           int64_t *total_samples_out, ced_frame_trace *trace, void *field_stream, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -870,6 +870,50 @@ def test_pipelined_frames_equal_sequential_frames(oracle, full_frame):
         assert out["total_samples"] == want[3] and torch.equal(out["rgb"][0], want[0])
 
 
+@pytest.mark.parametrize("name,max_samples", [("dnerf", 1024), ("dnerf", 20), ("hypernerf", 1024), ("dynerf", 64)])
+def test_render_frames_test_equals_frames_alone(oracle, name, max_samples):
+    """ced_render_frames_test: several frames (different cameras and times, one of them looking away from the scene)
+    share the launches of an iteration, each on its own schedule -- every frame's pixels and sample count are exactly
+    those of render_image_test on that frame alone.  max_samples = 20 / 64 end the frames' loops by the sample budget
+    (at different iterations) instead of by running out of rays."""
+    from ced_nerf_amd import synthetic as S
+    from ced_nerf_amd.model import DNGPradianceField
+    from ced_nerf_amd.nerfacc_api import OccGridEstimator
+    from ced_nerf_amd.utils import Rays, render_frames_test, render_image_test
+    W, H = 96, 72
+    sc = _scene(name, W, H, "trained", log2_hashmap_size=15)
+    cfg = sc["cfg"]
+    f = DNGPradianceField.from_params(sc["params"], DEV).eval()
+    est = OccGridEstimator(cfg["aabb"], cfg["grid_resolution"], cfg["grid_levels"]).to(DEV)
+    est.set_binaries(T(sc["binaries"]))
+    rk = dict(sc["render"]); rk["render_bkgd"] = T(rk["render_bkgd"])
+    frames = []
+    for k, (elev, az, radius) in enumerate([(30.0, 10.0, 1.0), (55.0, 140.0, 0.8), (5.0, 250.0, 1.6), (30.0, 40.0, 1.0),
+                                            (80.0, 300.0, 1.2)]):
+        c2w = S.look_at_c2w(cfg["radius"] * radius, elev, az, cfg["opengl"])
+        if k == 3:
+            c2w = c2w.copy(); c2w[:3, :3] = -c2w[:3, :3]                   # looks away: no sample at all
+        o, d = S.make_camera_rays(W, H, cfg["camera_angle_x"], c2w, cfg["opengl"])
+        frames.append((o, d, np.float32(k / 4.0)))
+    alone = [render_image_test(max_samples, f, est, Rays(T(o), T(d)), timestamps=torch.tensor([[t]], device=DEV), **rk)
+             for o, d, t in frames]
+    assert alone[3][3] == 0 and alone[0][3] != alone[1][3]
+    for n in (1, 2, 5):
+        rays = Rays(torch.stack([T(o) for o, _, _ in frames[:n]]), torch.stack([T(d) for _, d, _ in frames[:n]]))
+        ts = torch.tensor([t for _, _, t in frames[:n]], device=DEV)
+        for _ in range(2):                                             # the workspace is reused: no state may leak
+            rgb, op, dp, totals = render_frames_test(max_samples, f, est, rays, timestamps=ts, **rk)
+            torch.cuda.synchronize()
+            assert rgb.shape == (n, H, W, 3) and op.shape == (n, H, W, 1) and len(totals) == n
+            for k in range(n):
+                assert totals[k] == alone[k][3], (n, k, totals, [a[3] for a in alone])
+                assert torch.equal(rgb[k], alone[k][0]) and torch.equal(op[k], alone[k][1]) and torch.equal(dp[k], alone[k][2])
+    assert sum(a[3] for a in alone) > 5000
+    with pytest.raises(ValueError):
+        many = Rays(torch.zeros(9, 4, 4, 3, device=DEV), torch.ones(9, 4, 4, 3, device=DEV))
+        render_frames_test(64, f, est, many, timestamps=torch.zeros(9, device=DEV), **rk)
+
+
 def test_frame_to_uint8_bitexact(oracle):
     """the 8-bit frames of the video step (train_real.py:556-557) -- colours x 255 truncated and
     flipped along the width, depth min-max normalised -- bit-exact against the numpy statement, for ragged sizes,
