@@ -47,6 +47,9 @@ def parse():
                     help="per-launch HBM traffic of the field kernel from the rocprofv3 --pmc passes (tools/pmc_summary.py)")
     ap.add_argument("--regime", default="trained")
     ap.add_argument("--max-samples", type=int, default=1024)
+    ap.add_argument("--frames-per-call", type=int, default=int(os.environ.get("CED_FRAMES_PER_CALL", "3")),
+                    help="frames rendered by one native call (ced_render_frames_test): they share the launches of an "
+                         "iteration, each on its own schedule; 1 = ced_render_image_test per frame")
     ap.add_argument("--frames-in-flight", type=int, default=3,
                     help="independent frames rendered concurrently per GPU (own stream + host thread each)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -135,8 +138,16 @@ def main():
     # A step renders `lanes` x `world` frames of a turntable video (consecutive azimuths): every lane is
     # one frame per GPU, its rays dealt tile-cyclically over the ranks; the lanes run concurrently.
     lanes = max(1, args.frames_in_flight)
+    per_call = max(1, min(8, args.frames_per_call))
+    if per_call > 1:
+        # several frames per call need every rank's share of every frame group to be the same number of rays
+        # (true for 800x800 on 1/2/4/8 GPUs); otherwise fall back to one frame per call
+        ids = cdist.tile_cyclic_assignment(per_call * world, args.height, args.width, world)[1]
+        group = world * args.height * args.width
+        if len({len(s) for s in ids}) != 1 or any(len(set(np.bincount(s // group, minlength=per_call).tolist())) != 1 for s in ids):
+            per_call = 1
     tdt = np.float16 if args.table_dtype == "f16" else np.float32
-    n_frames = lanes * world
+    n_frames = lanes * per_call * world
     sc = S.make_scene(args.scene, args.width, args.height, args.regime, azim_deg=30.0, table_dtype=tdt)
     cfg = sc["cfg"]
 
@@ -157,9 +168,9 @@ def main():
     from ced_nerf_amd import ops
     lane_renderers, tracers = [], []
     for l in range(lanes):
-        fr = frames[l * world:(l + 1) * world]
+        fr = frames[l * per_call * world:(l + 1) * per_call * world]
         r = cdist.ShardedRenderer(field, est, world, rank, dev, max_samples=args.max_samples, render_kwargs=rk,
-                                  tile_order=os.environ.get("CED_TILE_ORDER", "1") != "0")
+                                  tile_order=os.environ.get("CED_TILE_ORDER", "1") != "0", units=per_call)
         r.set_rays(torch.stack([T(f["origins"]) for f in fr]), torch.stack([T(f["viewdirs"]) for f in fr]))
         # HIP events around every field launch; one event set per timed step so nothing is read back
         # (hipEventElapsedTime) inside the timed region
@@ -252,7 +263,7 @@ def main():
             t2sum = tt2.clone(); dist.all_reduce(t2sum, op=dist.ReduceOp.SUM)
             tt2 = torch.stack([t2max[0], t2sum[1]])
         others[prec] = {"value": float(tt2[1]) / float(tt2[0]), "unit": "samples/s", "steps": k,
-                        "ms_per_frame": 1e3 * float(tt2[0]) / k / lanes,
+                        "ms_per_frame": 1e3 * float(tt2[0]) / k / (lanes * per_call),
                         "rays_per_sec": n_frames * args.width * args.height * k / float(tt2[0])}
     field.set_mlp_precision(args.mlp_precision)
     field._descriptor()
@@ -266,9 +277,14 @@ def main():
     torch.cuda.synchronize()
     t1 = time.perf_counter()
     single_field = {"ms": 0.0, "launches": 0, "units": 0.0}
-    lane_renderers[0].tracer = tracers[0][0]
+    alone = lane_renderers[0]
+    if per_call > 1:                                # one frame (per GPU) per call, as ced_render_image_test renders it
+        alone = cdist.ShardedRenderer(field, est, world, rank, dev, max_samples=args.max_samples, render_kwargs=rk,
+                                      tile_order=os.environ.get("CED_TILE_ORDER", "1") != "0")
+        alone.set_rays(torch.stack([T(f["origins"]) for f in frames[:world]]), torch.stack([T(f["viewdirs"]) for f in frames[:world]]))
+    alone.tracer = tracers[0][0]
     for _ in range(5):
-        lane_renderers[0].render_local(ts)          # this rank's shard only: the other ranks have left by now
+        alone.render_local(ts)                      # this rank's shard only: the other ranks have left by now
         ms = tracers[0][0].field_ms()
         single_field["ms"] += sum(ms); single_field["launches"] += len(ms)
         single_field["units"] += float(sum(it["n_new"] for it in tracers[0][0].iterations()))
@@ -283,14 +299,16 @@ def main():
                   "f16": "f16 MLP operands, fp32 accumulate; rest f32"}[args.mlp_precision],
         "mlp_precision": args.mlp_precision, "data": "synthetic",
         "rays_per_sec": n_rays_step * args.steps / dt,
-        "ms_per_frame": 1e3 * dt / args.steps / lanes, "single_frame_latency_ms": single_ms,
+        "ms_per_frame": 1e3 * dt / args.steps / (lanes * per_call), "single_frame_latency_ms": single_ms,
         "samples_per_ray": samples_total / (n_rays_step * args.steps),
         "config": {"workload": f"{args.scene} {args.width}x{args.height} render_image_test max_samples={args.max_samples}, "
                                f"hash L=16 F=2 T=2^21 {'fp16' if fp16 else 'fp32'} table, 64-wide MLPs, "
                                f"{args.regime} params, occupancy 128^3 x{cfg['grid_levels']}",
-                   "frames_per_step": n_frames, "frames_in_flight_per_gpu": lanes, "rays_per_step": n_rays_step,
-                   "parallelism": f"{lanes} frame(s) in flight per GPU; each frame's rays tile-cyclic over {world} "
-                                  f"GPU(s) + all-gather of pixels"},
+                   "frames_per_step": n_frames, "frames_in_flight_per_gpu": lanes * per_call, "frames_per_call": per_call,
+                   "rays_per_step": n_rays_step,
+                   "parallelism": f"{lanes} call(s) in flight per GPU x {per_call} frame(s) per call, every frame on its own "
+                                  f"render_image_test schedule; each frame's rays tile-cyclic over {world} GPU(s) + "
+                                  f"all-gather of pixels"},
     }
     fk = prof.get("field", None)
     if fk and fk["launches"] > 0:

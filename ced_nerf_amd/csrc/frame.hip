@@ -169,7 +169,6 @@ struct MarchArgs {
     int32_t *ray_idx;
     int32_t *packed;               // [n_rays, 2] (start, count)
     unsigned long long *counter;   // samples reserved so far in this iteration
-    unsigned long long *frame_samples;   // [n_frames] samples of each frame in this iteration
 };
 
 // Workgroup of T threads (T/64 waves).  Each ray marches once and stages its (t_start, t_end) pairs
@@ -226,7 +225,6 @@ __global__ __launch_bounds__(256) void march_alloc_kernel(MarchArgs A)
         int run = 0;
         for (int w = 0; w < n_waves; ++w) { int t = wave_tot[w]; wave_tot[w] = run; run += t; }
         block_base = run > 0 ? (long long)atomicAdd(A.counter, (unsigned long long)run) : 0;
-        if (run > 0) atomicAdd(A.frame_samples + f, (unsigned long long)run);
     }
     __syncthreads();
     const int64_t start = (int64_t)block_base + wave_tot[wave] + (incl - n);
@@ -272,7 +270,7 @@ __global__ __launch_bounds__(256) void frame_composite_kernel(BatchMap map, cons
                                                               float *__restrict__ opacity, float *__restrict__ depth,
                                                               float opc_thres)
 {
-    __shared__ int wave_alive[4];
+    __shared__ int wave_alive[4], wave_samples[4];
     __shared__ long long block_base;
     const int64_t s0 = (int64_t)blockIdx.x * blockDim.x;
     const int f = frame_of_slot(map, s0);
@@ -340,11 +338,23 @@ __global__ __launch_bounds__(256) void frame_composite_kernel(BatchMap map, cons
     const unsigned long long ballot = __ballot(alive);
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     if (lane == 0) wave_alive[wave] = __builtin_popcountll(ballot);
+    // several frames per call: the frame's sample count of this iteration rides in the high word of the same atomic
+    // that reserves the survivors' range (low word), so the per-frame totals cost no extra atomic
+    const bool count_samples = map.n_frames > 1;
+    if (count_samples) {
+        int wsum = cnt;
+#pragma unroll
+        for (int off = 32; off >= 1; off >>= 1) wsum += __shfl_xor(wsum, off, 64);
+        if (lane == 0) wave_samples[wave] = wsum;
+    }
     __syncthreads();
     if (threadIdx.x == 0) {
         int run = 0;
         for (int w = 0; w < 4; ++w) { int t = wave_alive[w]; wave_alive[w] = run; run += t; }
-        block_base = run > 0 ? (long long)atomicAdd(next_count + f, (unsigned long long)run) : 0;
+        unsigned long long add = (unsigned long long)run;
+        if (count_samples)
+            add += (unsigned long long)(wave_samples[0] + wave_samples[1] + wave_samples[2] + wave_samples[3]) << 32;
+        block_base = add != 0 ? (long long)(atomicAdd(next_count + f, add) & 0xffffffffull) : 0;
     }
     __syncthreads();
     if (alive) {
@@ -375,16 +385,16 @@ __global__ void frame_publish_kernel(const unsigned long long *__restrict__ it_c
                                      const unsigned long long *__restrict__ next_counters, int n_frames, long long *host,
                                      long long seq)
 {
-    // per-iteration counter block: [0] samples reserved, [2+f] rays of frame f alive entering the iteration,
-    // [2+F+f] samples of frame f
+    // per-iteration counter block: [0] samples reserved in the iteration; [2+f]: low word = rays of frame f alive
+    // entering the iteration, high word (several frames per call) = samples of frame f in the PREVIOUS iteration
     long long alive_next = 0;
-    for (int f = 0; f < n_frames; ++f) alive_next += (long long)next_counters[2 + f];
+    for (int f = 0; f < n_frames; ++f) alive_next += (long long)(next_counters[2 + f] & 0xffffffffull);
     host[0] = (long long)it_counters[0];    // samples reserved in this iteration
     host[1] = alive_next;                   // rays alive entering the next iteration
     if (n_frames > 1)
         for (int f = 0; f < n_frames; ++f) {
-            host[3 + f] = (long long)next_counters[2 + f];
-            host[3 + n_frames + f] = (long long)it_counters[2 + n_frames + f];
+            host[3 + f] = (long long)(next_counters[2 + f] & 0xffffffffull);
+            host[3 + n_frames + f] = (long long)(next_counters[2 + f] >> 32);
         }
     __threadfence_system();
     __hip_atomic_store(&host[2], seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
@@ -395,7 +405,7 @@ static inline size_t align_up(size_t x) { return (x + 255) & ~(size_t)255; }
 struct FrameWorkspace {
     float *t_sorted; int64_t *t_indices; uint8_t *hits; float *near; int32_t *packed;
     int32_t *alive_a, *alive_b;     // double-buffered list of alive ray ids
-    unsigned long long *counters;   // [iters+2][2+2F]: see frame_publish_kernel
+    unsigned long long *counters;   // [iters+2][2+F]: see frame_publish_kernel
     float *ts_ray;                  // per-ray time of a multi-frame call
     float *t0, *t1; int32_t *ridx; float *sigma, *rgbs;
     uint8_t *brick_any, *brick_dil;
@@ -415,7 +425,7 @@ static FrameWorkspace carve(void *base, int64_t n, int m, int64_t cap, int max_i
     w.packed = (int32_t *)take((size_t)n * 8);
     w.alive_a = (int32_t *)take((size_t)n * 4);
     w.alive_b = (int32_t *)take((size_t)n * 4);
-    w.counters = (unsigned long long *)take((size_t)(max_iters + 2) * (2 + 2 * n_frames) * 8);
+    w.counters = (unsigned long long *)take((size_t)(max_iters + 2) * (2 + n_frames) * 8);
     w.ts_ray = (float *)take(per_ray_times ? (size_t)n * 4 : 0);
     w.t0 = (float *)take((size_t)cap * 4);
     w.t1 = (float *)take((size_t)cap * 4);
@@ -488,7 +498,7 @@ static int render_frames_impl(const ced_field_desc *field, int n_frames, int64_t
                        W.t_sorted, W.t_indices, W.hits, W.near, rgb, opacity, depth);
     if (frame_times)
         hipLaunchKernelGGL(frame_times_kernel, grd, blk, 0, stream, n_rays, (int)rays_per_frame, frame_times, W.ts_ray);
-    const size_t cstride = 2 + 2 * (size_t)n_frames;              // counters per iteration (see frame_publish_kernel)
+    const size_t cstride = 2 + (size_t)n_frames;                  // counters per iteration (see frame_publish_kernel)
     if (hipMemsetAsync(W.counters, 0, (size_t)(max_samples + 3) * cstride * 8, stream) != hipSuccess)
         return check_launch("render_image_test (memset)");
     const int nb = (res + kBrick - 1) / kBrick;
@@ -539,7 +549,7 @@ static int render_frames_impl(const ced_field_desc *field, int n_frames, int64_t
                      GridSpec{ binaries, aabbs, n_grids, res, step_size, cone_angle, max_limit,
                                g_march_early_out ? W.brick_dil : nullptr, nb, it > 0 ? 1 : 0 },
                      W.near, far_plane, cur_list, B, W.t_sorted, W.t_indices, W.hits, W.t0, W.t1, W.ridx, W.packed,
-                     counter, it_counters + 2 + n_frames };
+                     counter };
         // only alive rays get a lane; 128 rays per workgroup (CED_MARCH_THREADS): a workgroup lives as long as its
         // slowest ray (its waves meet at the range reservation), while one reservation still serves 128 rays
         static const int threads_env = [] {

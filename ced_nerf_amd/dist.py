@@ -53,7 +53,7 @@ class ShardedRenderer:
 
     def __init__(self, field, estimator, world: int, rank: int, device, max_samples: int = 1024,
                  render_kwargs: Optional[Dict] = None, render_fn: Optional[Callable] = None,
-                 force_collective: bool = False, tile_order: bool = False):
+                 force_collective: bool = False, tile_order: bool = False, units: int = 1):
         self.field, self.estimator = field, estimator
         self.world, self.rank, self.device = world, rank, device
         self.max_samples = max_samples
@@ -67,12 +67,26 @@ class ShardedRenderer:
         # tile, not a 64-pixel strip: more coherent marching depths and hash cells) and un-permute the pixels
         self.tile_order = tile_order
         self.unpermute = None
+        # units > 1: the F frames handed to set_rays are `units` groups of F // units consecutive frames, and one
+        # native call (ced_render_frames_test) renders this rank's share of all the groups through shared launches
+        # while every group keeps its own render_image_test schedule.  With one GPU and F == units a group is a
+        # frame, so every frame is rendered exactly as if alone -- only with `units` times larger launches.
+        self.units = int(units)
+        assert 1 <= self.units <= 8, "units must be 1..8"
 
     def _hip_render(self, rays_o, rays_d, timestamps):
-        from .utils import Rays, render_image_test
-        return render_image_test(self.max_samples, self.field, self.estimator, Rays(rays_o, rays_d),
-                                 timestamps=timestamps, tracer=self.tracer, field_stream=self.field_stream,
-                                 **self.render_kwargs)
+        from .utils import Rays, render_frames_test, render_image_test
+        if self.units == 1:
+            return render_image_test(self.max_samples, self.field, self.estimator, Rays(rays_o, rays_d),
+                                     timestamps=timestamps, tracer=self.tracer, field_stream=self.field_stream,
+                                     **self.render_kwargs)
+        u = self.units
+        ts = timestamps.reshape(-1).float()
+        ts = ts.expand(u).contiguous() if ts.numel() == 1 else ts      # one time for all groups, or one per group
+        rgb, op, dp, totals = render_frames_test(
+            self.max_samples, self.field, self.estimator, Rays(rays_o.view(u, -1, 3), rays_d.view(u, -1, 3)), timestamps=ts,
+            tracer=self.tracer, field_stream=self.field_stream, **self.render_kwargs)
+        return rgb.view(-1, 3), op.view(-1, 1), dp.view(-1, 1), sum(totals)
 
     def set_rays(self, origins: torch.Tensor, viewdirs: torch.Tensor) -> None:
         assert origins.ndim == 4 and origins.shape == viewdirs.shape, "rays must be [F,H,W,3]"
@@ -84,6 +98,13 @@ class ShardedRenderer:
             return
         self.shape = (F, H, W)
         self._ray_index = None
+        if self.units > 1:
+            if F % self.units:
+                raise ValueError(f"{F} frames do not split into {self.units} equal groups")
+            ids = tile_cyclic_assignment(F, H, W, self.world)[1][self.rank]
+            per_group = np.bincount(ids // ((F // self.units) * H * W), minlength=self.units)
+            if len(set(per_group.tolist())) != 1 or any(len(s) != len(ids) for s in tile_cyclic_assignment(F, H, W, self.world)[1]):
+                raise ValueError("the ray shards of the frame groups are not of equal size: use units=1 for this image size")
         if self.world == 1 and not self.force_collective:
             self.n_local = self.n_pad = o.shape[0]
             self.gather_index = None

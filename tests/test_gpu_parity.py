@@ -914,6 +914,49 @@ def test_render_frames_test_equals_frames_alone(oracle, name, max_samples):
         render_frames_test(64, f, est, many, timestamps=torch.zeros(9, device=DEV), **rk)
 
 
+def test_sharded_renderer_units_equal_frames_alone(oracle):
+    """ShardedRenderer(units=3) (bench.py's default at one GPU: three frames per native call, rays in 8x8-tile order,
+    pixels un-permuted): every frame equals render_image_test on it alone; also through frames in flight."""
+    from ced_nerf_amd import synthetic as S
+    from ced_nerf_amd.dist import PipelinedRenderer, ShardedRenderer
+    from ced_nerf_amd.model import DNGPradianceField
+    from ced_nerf_amd.nerfacc_api import OccGridEstimator
+    from ced_nerf_amd.utils import Rays, render_image_test
+    W, H = 96, 72
+    sc = _scene("dnerf", W, H, "trained", log2_hashmap_size=15)
+    cfg = sc["cfg"]
+    f = DNGPradianceField.from_params(sc["params"], DEV).eval()
+    est = OccGridEstimator(cfg["aabb"], cfg["grid_resolution"], cfg["grid_levels"]).to(DEV)
+    est.set_binaries(T(sc["binaries"]))
+    rk = dict(sc["render"]); rk["render_bkgd"] = T(rk["render_bkgd"])
+    ts = T(sc["timestamps"])
+    lanes, alone = [], []
+    for l in range(2):
+        os_, ds_ = [], []
+        for k in range(3):
+            c2w = S.look_at_c2w(cfg["radius"], 30.0, 20.0 + 25.0 * (3 * l + k), cfg["opengl"])
+            o, d = S.make_camera_rays(W, H, cfg["camera_angle_x"], c2w, cfg["opengl"])
+            os_.append(T(o)); ds_.append(T(d))
+            alone.append(render_image_test(1024, f, est, Rays(T(o), T(d)), timestamps=ts, **rk))
+        r = ShardedRenderer(f, est, 1, 0, torch.device(DEV), max_samples=1024, render_kwargs=rk, tile_order=True, units=3)
+        r.set_rays(torch.stack(os_), torch.stack(ds_))
+        lanes.append(r)
+    out = lanes[0].render(ts)
+    assert out["total_samples"] == sum(a[3] for a in alone[:3])
+    for k in range(3):
+        assert torch.equal(out["rgb"][k], alone[k][0]) and torch.equal(out["depth"][k], alone[k][2])
+    pipe = PipelinedRenderer(lanes)
+    for row in pipe.render_steps(ts, 3):
+        torch.cuda.synchronize()
+        for l, o in enumerate(row):
+            for k in range(3):
+                assert torch.equal(o["rgb"][k], alone[3 * l + k][0]) and torch.equal(o["opacity"][k], alone[3 * l + k][1])
+    pipe.restore_field_blocks()
+    with pytest.raises(ValueError):
+        bad = ShardedRenderer(f, est, 1, 0, torch.device(DEV), render_kwargs=rk, units=2)
+        bad.set_rays(torch.stack(os_), torch.stack(ds_))                       # 3 frames do not split into 2 groups
+
+
 def test_frame_to_uint8_bitexact(oracle):
     """the 8-bit frames of the video step (train_real.py:556-557) -- colours x 255 truncated and
     flipped along the width, depth min-max normalised -- bit-exact against the numpy statement, for ragged sizes,
@@ -1127,7 +1170,7 @@ def test_bench_two_rank_rehearsal():
     assert len(lines) == 1, out.stdout[-2000:]
     d = json.loads(lines[0])
     assert d["n_gpus"] == 2 and d["steps"] == 2 and d["scaling"] == "weak" and d["value"] > 0
-    assert d["config"]["frames_per_step"] == 6 and "f16x2" in d["other_mlp_precisions"]
+    assert d["config"]["frames_per_step"] == 18 and d["config"]["frames_per_call"] == 3 and "f16x2" in d["other_mlp_precisions"]
     assert d["roofline"]["bound"] == "mfma" and 0 < d["roofline"]["frac"] < 1
 
 
