@@ -53,6 +53,9 @@ def parse():
     ap.add_argument("--frames-in-flight", type=int, default=3,
                     help="independent frames rendered concurrently per GPU (own stream + host thread each)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-single-frame", action="store_true",
+                    help="skip the one-frame-alone latency measurement after the timed region (profiling runs: every "
+                         "field launch of the process is then one of the timed kind)")
     ap.add_argument("--cpu-stride", type=int, default=1, help="pixel stride of the CPU-baseline ray sample")
     ap.add_argument("--cpu-passes", type=int, default=3, help="how many times the CPU baseline renders its sample")
     ap.add_argument("--torch-stride", type=int, default=4,
@@ -277,19 +280,24 @@ def main():
     torch.cuda.synchronize()
     t1 = time.perf_counter()
     single_field = {"ms": 0.0, "launches": 0, "units": 0.0}
-    alone = lane_renderers[0]
-    if per_call > 1:                                # one frame (per GPU) per call, as ced_render_image_test renders it
-        alone = cdist.ShardedRenderer(field, est, world, rank, dev, max_samples=args.max_samples, render_kwargs=rk,
-                                      tile_order=os.environ.get("CED_TILE_ORDER", "1") != "0")
-        alone.set_rays(torch.stack([T(f["origins"]) for f in frames[:world]]), torch.stack([T(f["viewdirs"]) for f in frames[:world]]))
-    alone.tracer = tracers[0][0]
-    for _ in range(5):
-        alone.render_local(ts)                      # this rank's shard only: the other ranks have left by now
-        ms = tracers[0][0].field_ms()
-        single_field["ms"] += sum(ms); single_field["launches"] += len(ms)
-        single_field["units"] += float(sum(it["n_new"] for it in tracers[0][0].iterations()))
-    torch.cuda.synchronize()
-    single_ms = (time.perf_counter() - t1) / 5 * 1e3
+    single_ms = None
+    if not args.no_single_frame:
+        alone = lane_renderers[0]
+        if per_call > 1:                                # one frame (per GPU) per call, as ced_render_image_test renders it
+            alone = cdist.ShardedRenderer(field, est, world, rank, dev, max_samples=args.max_samples, render_kwargs=rk,
+                                          tile_order=os.environ.get("CED_TILE_ORDER", "1") != "0")
+            alone.set_rays(torch.stack([T(f["origins"]) for f in frames[:world]]), torch.stack([T(f["viewdirs"]) for f in frames[:world]]))
+        alone.tracer = tracers[0][0]
+        alone.render_local(ts)                          # first call on this stream allocates its workspace
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        for _ in range(5):
+            alone.render_local(ts)                      # this rank's shard only: the other ranks have left by now
+            ms = tracers[0][0].field_ms()
+            single_field["ms"] += sum(ms); single_field["launches"] += len(ms)
+            single_field["units"] += float(sum(it["n_new"] for it in tracers[0][0].iterations()))
+        torch.cuda.synchronize()
+        single_ms = (time.perf_counter() - t1) / 5 * 1e3
     fp16 = sc["params"]["hash"]["table"].dtype == np.float16
     line = {
         "metric": "samples_per_sec (render_image_test, 800x800 D-NeRF lego-shaped synthetic)",
@@ -343,9 +351,10 @@ def main():
         common = {"avg_launch_ms": avg_ms, "launches": fk["launches"], "samples_per_launch": samples_per_launch,
                   "avg_launch_ms_raw": raw_avg_ms,
                   "field_busy_over_wall": busy_ms / (1e3 * dt * min(args.steps, 24) / args.steps),
-                  "note": "%d frame(s) in flight: avg_launch_ms = (time with a field kernel executing) / launches; "
-                          "avg_launch_ms_raw = mean begin->end of a launch (overlapping launches share the chip; this is "
-                          "what rocprofv3 --stats lists); roofline_single_frame = the kernel with one frame in flight" % lanes}
+                  "note": "%d call(s) in flight x %d frame(s) per call: avg_launch_ms = (time with a field kernel executing) "
+                          "/ launches; avg_launch_ms_raw = mean begin->end of a launch (overlapping launches share the chip; "
+                          "this is what rocprofv3 --stats lists); roofline_single_frame = the kernel with one frame alone"
+                          % (lanes, per_call)}
         r_mfma = {"kernel": f"{kname} (fused DNGPradianceField forward, mlp_precision={args.mlp_precision})",
                   "bound": "mfma", "achieved": tflops, "peak": mfma_peak, "unit": "TFLOP/s", "frac": tflops / mfma_peak,
                   "traffic": traffic, "alg_flops_per_sample": ALG_FLOPS_PER_SAMPLE}

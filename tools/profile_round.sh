@@ -13,7 +13,8 @@ for prec in f32 f16x2; do
   # 1. the bench line itself (not under the profiler)
   timeout -k 10 300 python3 $ARGS > $OUT/${TAG}_${prec}_bench.json 2> $OUT/${TAG}_${prec}_bench.err
   echo "bench $prec done"
-  # 2. per-kernel times
+  # 2. per-kernel times (profiled runs skip the one-frame-alone epilogue: all field launches are of the timed kind)
+  ARGS="$ARGS --no-single-frame"
   timeout -k 10 400 rocprofv3 --kernel-trace --stats -d $OUT/kt_$prec -o kt --output-format csv -- python3 $ARGS > $OUT/${TAG}_${prec}_bench_under_rocprof.json 2> $OUT/kt_$prec.err
   cp $(ls $OUT/kt_$prec/*kernel_stats.csv | head -1) $OUT/${TAG}_${prec}_kernel_stats.csv
   echo "kernel trace $prec done"
