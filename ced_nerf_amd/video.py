@@ -29,43 +29,53 @@ def frame_to_uint8(rgb: torch.Tensor, depth: torch.Tensor, flip_w: bool = True) 
 @torch.no_grad()
 def render_video(radiance_field, estimator, rays_of_frame: Callable[[int], Rays], timestamps_of_frame: Callable[[int], torch.Tensor],
                  n_frames: int, max_samples: int = 1024, render_kwargs: Optional[Dict] = None, frames_in_flight: int = 3,
-                 flip_w: bool = True, to_host: bool = False, keep_float: bool = False) -> List[Dict]:
+                 flip_w: bool = True, to_host: bool = False, keep_float: bool = False, frames_per_call: int = 1) -> List[Dict]:
     """Render frames 0..n_frames-1 of a path.
 
     rays_of_frame(i) -> Rays with [H,W,3] device tensors (e.g. `cameras.pinhole_rays(K, c2w_i, W, H)`; it is called on
     the rendering thread of the frame's lane with that lane's stream current, so device ray generation overlaps the
     other frames); timestamps_of_frame(i) -> the frame's [1,1] time.  Returns one dict per frame: `rgb` uint8 [H,W,3],
     `depth` uint8 [H,W] (torch tensors on the device, or numpy arrays with to_host=True), `n_samples`; with
-    keep_float=True also the float images `rgb_f32`, `opacity_f32`, `depth_f32`."""
+    keep_float=True also the float images `rgb_f32`, `opacity_f32`, `depth_f32`.
+    frames_per_call > 1 (up to 8): that many consecutive frames go through one native call (ced_render_frames_test:
+    shared launches, each frame on its own schedule -- same pixels, larger launches); `n_samples` is then reported
+    per call on its first frame's entry and the others carry None."""
     if n_frames <= 0:
         return []
     device = radiance_field.aabb.device if hasattr(radiance_field, "aabb") else torch.device("cuda")
-    n_lanes = max(1, min(int(frames_in_flight), n_frames))
+    per_call = max(1, min(8, int(frames_per_call)))
+    n_calls = (n_frames + per_call - 1) // per_call
+    n_lanes = max(1, min(int(frames_in_flight), n_calls))
     lanes = [ShardedRenderer(radiance_field, estimator, 1, 0, device, max_samples=max_samples,
-                             render_kwargs=render_kwargs, tile_order=True) for _ in range(n_lanes)]
+                             render_kwargs=render_kwargs, tile_order=True, units=per_call) for _ in range(n_lanes)]
     pipe = PipelinedRenderer(lanes)
-    n_steps = (n_frames + n_lanes - 1) // n_lanes
-    frame_of = lambda lane, step: min(step * n_lanes + lane, n_frames - 1)     # the tail of the last step repeats the last frame
+    n_steps = (n_calls + n_lanes - 1) // n_lanes
+    # frames of the call (lane, step); the tail of the path repeats the last frame
+    frames_of = lambda lane, step: [min((step * n_lanes + lane) * per_call + k, n_frames - 1) for k in range(per_call)]
 
     def before_frame(lane, step):
-        r = rays_of_frame(frame_of(lane, step))
-        lanes[lane].set_rays(r.origins[None], r.viewdirs[None])
+        rs = [rays_of_frame(i) for i in frames_of(lane, step)]
+        lanes[lane].set_rays(torch.stack([r.origins for r in rs]), torch.stack([r.viewdirs for r in rs]))
+
+    def times(lane, step):
+        return torch.cat([timestamps_of_frame(i).reshape(-1)[:1] for i in frames_of(lane, step)])
 
     try:
-        steps = pipe.render_steps(lambda lane, step: timestamps_of_frame(frame_of(lane, step)), n_steps, before_frame)
+        steps = pipe.render_steps(times, n_steps, before_frame)
     finally:
         pipe.restore_field_blocks()
     frames = []
     for step, row in enumerate(steps):
         for lane, out in enumerate(row):
-            i = step * n_lanes + lane
-            if i >= n_frames:
-                break
-            rgb, depth = out["rgb"][0], out["depth"][0]
-            rgb8, d8 = frame_to_uint8(rgb, depth, flip_w)
-            f = {"rgb": rgb8.cpu().numpy() if to_host else rgb8, "depth": d8.cpu().numpy() if to_host else d8,
-                 "n_samples": int(out["total_samples"])}
-            if keep_float:
-                f.update(rgb_f32=rgb, opacity_f32=out["opacity"][0], depth_f32=depth)
-            frames.append(f)
+            for k in range(per_call):
+                i = (step * n_lanes + lane) * per_call + k
+                if i >= n_frames:
+                    break
+                rgb, depth = out["rgb"][k], out["depth"][k]
+                rgb8, d8 = frame_to_uint8(rgb, depth, flip_w)
+                f = {"rgb": rgb8.cpu().numpy() if to_host else rgb8, "depth": d8.cpu().numpy() if to_host else d8,
+                     "n_samples": int(out["total_samples"]) if (per_call == 1 or k == 0) else None}
+                if keep_float:
+                    f.update(rgb_f32=rgb, opacity_f32=out["opacity"][k], depth_f32=depth)
+                frames.append(f)
     return frames

@@ -1018,6 +1018,13 @@ def test_render_video_equals_frames_rendered_alone(oracle):
             assert torch.equal(fr["rgb_f32"], want[0]) and torch.equal(fr["depth_f32"], want[2])
             assert_bitexact(N(fr["rgb"]), oracle.frame_to_rgb8(N(want[0])), "video rgb8")
             assert_bitexact(N(fr["depth"]), oracle.depth_to_u8(N(want[2])[..., 0]), "video depth8")
+    # two frames per native call (5 frames -> 3 calls, the last one padded), 2 calls in flight
+    frames = render_video(f, est, rays_of, lambda i: times[i], n_frames, render_kwargs=rk, frames_in_flight=2,
+                          frames_per_call=2, keep_float=True)
+    torch.cuda.synchronize()
+    assert len(frames) == n_frames and frames[0]["n_samples"] == alone[0][3] + alone[1][3] and frames[1]["n_samples"] is None
+    for fr, want in zip(frames, alone):
+        assert torch.equal(fr["rgb_f32"], want[0]) and torch.equal(fr["opacity_f32"], want[1]) and torch.equal(fr["depth_f32"], want[2])
     host = render_video(f, est, rays_of, lambda i: times[i], 2, render_kwargs=rk, to_host=True)
     assert isinstance(host[0]["rgb"], np.ndarray) and host[1]["rgb"].shape == (H, W, 3)
     # a failure on a lane's thread surfaces as an exception instead of a hang
