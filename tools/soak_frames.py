@@ -8,19 +8,28 @@ from ced_nerf_amd.model import DNGPradianceField
 from ced_nerf_amd.nerfacc_api import OccGridEstimator
 dev = "cuda:0"; T = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)
 reps = int(os.environ.get("REPS", "100"))
+units = int(os.environ.get("UNITS", "1"))       # frames per native call (ced_render_frames_test)
 sc = S.make_scene("dnerf", 800, 800, "trained"); cfg = sc["cfg"]
 est = OccGridEstimator(cfg["aabb"], 128, cfg["grid_levels"]).to(dev); est.set_binaries(T(sc["binaries"]))
 rk = dict(sc["render"]); rk["render_bkgd"] = T(rk["render_bkgd"]); ts = T(sc["timestamps"])
 for prec in ("f32", "f16x2", "f16"):
     f = DNGPradianceField.from_params(sc["params"], dev, mlp_precision=prec).eval()
-    lanes = []
+    lanes, singles = [], []
     for k in range(3):
-        c2w = S.look_at_c2w(cfg["radius"], 30.0, 30.0 + 12.0 * k, cfg["opengl"])
-        o, d = S.make_camera_rays(800, 800, cfg["camera_angle_x"], c2w, cfg["opengl"])
-        r = ShardedRenderer(f, est, 1, 0, torch.device(dev), max_samples=1024, render_kwargs=rk, tile_order=True)
-        r.set_rays(T(o)[None], T(d)[None]); lanes.append(r)
+        os_, ds_ = [], []
+        for u in range(units):
+            c2w = S.look_at_c2w(cfg["radius"], 30.0, 30.0 + 12.0 * (k * units + u), cfg["opengl"])
+            o, d = S.make_camera_rays(800, 800, cfg["camera_angle_x"], c2w, cfg["opengl"])
+            os_.append(T(o)); ds_.append(T(d))
+            one = ShardedRenderer(f, est, 1, 0, torch.device(dev), max_samples=1024, render_kwargs=rk, tile_order=True)
+            one.set_rays(T(o)[None], T(d)[None]); singles.append(one)
+        r = ShardedRenderer(f, est, 1, 0, torch.device(dev), max_samples=1024, render_kwargs=rk, tile_order=True, units=units)
+        r.set_rays(torch.stack(os_), torch.stack(ds_)); lanes.append(r)
     PipelinedRenderer.restore_field_blocks()
-    ref = [l.render(ts) for l in lanes]                   # one at a time, full-chip launches
+    alone = [l.render(ts) for l in singles]              # one frame at a time, full-chip launches
+    ref = [dict(rgb=torch.cat([alone[k * units + u]["rgb"] for u in range(units)]),
+                depth=torch.cat([alone[k * units + u]["depth"] for u in range(units)]),
+                total_samples=sum(alone[k * units + u]["total_samples"] for u in range(units))) for k in range(3)]
     pipe = PipelinedRenderer(lanes)
     bad = 0
     for _ in range(reps):
@@ -29,4 +38,4 @@ for prec in ("f32", "f16x2", "f16"):
         for a, b in zip(outs, ref):
             if not (torch.equal(a["rgb"], b["rgb"]) and torch.equal(a["depth"], b["depth"]) and a["total_samples"] == b["total_samples"]):
                 bad += 1
-    print(f"{prec}: {reps} pipelined steps x 3 frames, {bad} frames differ from the one-at-a-time render", flush=True)
+    print(f"{prec}: {reps} pipelined steps x 3 calls x {units} frame(s), {bad} calls differ from the one-frame-at-a-time render", flush=True)
