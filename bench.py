@@ -1,16 +1,22 @@
 """Benchmark of the rendering hot path on MI355X (contract: see the task brief / DESIGN.md section Measurement).
 
-One step = one full-frame `render_image_test` (cednerf/utils.py:153-318) of the BASELINE.json
+One frame = one full-frame `render_image_test` (cednerf/utils.py:153-318) of the BASELINE.json
 config-2 workload: 800x800 D-NeRF "lego"-shaped synthetic scene, hash L=16 F=2 T=2^21 fp32 table,
-64-wide MLPs, "trained-like" parameters, max_samples=1024.  With N GPUs every step renders N such
-frames (consecutive camera azimuths of a video render); their rays are dealt tile-cyclically over
-the ranks and the pixels are all-gathered over RCCL, so per-GPU work is fixed (weak scaling).
+64-wide MLPs, "trained-like" parameters, max_samples=1024.  A step renders 3 calls in flight x 3 frames
+per call x N GPUs such frames (consecutive camera azimuths of a video render), every frame on its own
+render_image_test schedule; with N GPUs their rays are dealt tile-cyclically over the ranks and the pixels
+are all-gathered over RCCL, so per-GPU work is fixed (weak scaling).
 """
 import argparse
 import json
 import os
 import sys
 import time
+
+# HIP multiplexes a process's streams onto 4 hardware queues by default, and streams that share a queue serialise.
+# A rank drives 3 call streams + the gather stream + the default stream: give every one its own queue (read by the HIP
+# runtime when it initialises, i.e. before the first torch.cuda call; measured: 4 lanes lose 15-20 % without it).
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
 
 import numpy as np
 import torch

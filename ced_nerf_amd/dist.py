@@ -195,6 +195,10 @@ class PipelinedRenderer:
     are exactly those of rendering the frames one at a time.  Collectives are issued afterwards by
     the calling thread, lane by lane, i.e. in the same order on every rank.
 
+    Streams: every lane has its own stream (plus one for the gathers).  HIP maps a process's streams onto 4 hardware
+    queues by default and streams sharing a queue serialise: with more than 3 lanes, or 3 lanes and async_gather, export
+    GPU_MAX_HW_QUEUES=8 before the process initialises HIP (bench.py does).
+
     async_gather=True (multi-rank video rendering): the gathers and the un-permute run on a communication
     stream of their own and `render` returns without waiting for them, so the exchange of one step overlaps
     the marching / field kernels of the next; the returned images are valid after `wait_gathers()` (or a
