@@ -216,7 +216,9 @@ def main():
     else:
         # the K steps as a stream: lanes do not wait for each other between steps (PipelinedRenderer.render_steps)
         def before_frame(l, s_):
-            lane_renderers[l].tracer = tracers[l][s_ % len(tracers[l])]
+            # the first min(steps, 24) steps of every lane are traced (the lanes start together, so their traced
+            # windows coincide); later steps run untraced
+            lane_renderers[l].tracer = tracers[l][s_] if s_ < len(tracers[l]) else None
         rows = renderer.render_steps(ts, args.steps, before_frame=before_frame)
         samples_local = sum(o["local_samples"] for row in rows for o in row)
     torch.cuda.synchronize()
@@ -232,6 +234,7 @@ def main():
             field_samples[0] += sum(it["n_new"] for it in tr.iterations())
     # time during which at least one field kernel was executing (frames in flight overlap their launches)
     intervals.sort()
+    span_ms = (max(e for _, e in intervals) - intervals[0][0]) if intervals else 0.0      # window the traced launches span
     busy_ms, cur_b, cur_e = 0.0, None, None
     for b, e in intervals:
         if cur_e is None or b > cur_e:
@@ -356,7 +359,7 @@ def main():
         kname = "field_kernel" if exact else "field_half_kernel"
         common = {"avg_launch_ms": avg_ms, "launches": fk["launches"], "samples_per_launch": samples_per_launch,
                   "avg_launch_ms_raw": raw_avg_ms,
-                  "field_busy_over_wall": busy_ms / (1e3 * dt * min(args.steps, 24) / args.steps),
+                  "field_busy_over_wall": busy_ms / max(span_ms, 1e-9),
                   "note": "%d call(s) in flight x %d frame(s) per call: avg_launch_ms = (time with a field kernel executing) "
                           "/ launches; avg_launch_ms_raw = mean begin->end of a launch (overlapping launches share the chip; "
                           "this is what rocprofv3 --stats lists); roofline_single_frame = the kernel with one frame alone"

@@ -8,15 +8,17 @@ from ced_nerf_amd.model import DNGPradianceField
 from ced_nerf_amd.nerfacc_api import OccGridEstimator
 from ced_nerf_amd.utils import Rays, render_image_test
 dev = "cuda:0"; T = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)
-sc = S.make_scene("dnerf", 800, 800, "trained"); cfg = sc["cfg"]
+scene = sys.argv[1] if len(sys.argv) > 1 else "dnerf"
+W, H = {"dnerf": (800, 800), "hypernerf": (536, 960), "dynerf": (1352, 1014)}[scene]
+sc = S.make_scene(scene, W, H, "trained"); cfg = sc["cfg"]
 f = DNGPradianceField.from_params(sc["params"], dev).eval()
-est = OccGridEstimator(cfg["aabb"], 128, cfg["grid_levels"]).to(dev); est.set_binaries(T(sc["binaries"]))
+est = OccGridEstimator(cfg["aabb"], cfg["grid_resolution"], cfg["grid_levels"]).to(dev); est.set_binaries(T(sc["binaries"]))
 rk = dict(sc["render"]); rk["render_bkgd"] = T(rk["render_bkgd"])
 rays = Rays(T(sc["origins"]), T(sc["viewdirs"])); ts = T(sc["timestamps"])
 L = _lib.lib()
 names = ["prologue", "segment select", "skip-march", "DDA set-up", "brick probes", "look-ahead DDA", "occupancy wait + emission", "reserve + copy-out"]
 prev = None
-for max_samples in (1, 2, 4, 7, 11, 17, 26, 41, 71, 132, 1024):      # cumulative: iteration k is the difference
+for max_samples in ((1, 2, 4, 7, 11, 17, 26, 41, 71, 132, 1024) if scene == "dnerf" else (4, 34, 1024)):      # cumulative: iteration k is the difference
     buf = (C.c_ulonglong * 16)()
     L.ced_debug_march_profile(None, 1)
     render_image_test(max_samples, f, est, rays, timestamps=ts, **rk)
