@@ -63,6 +63,31 @@ def test_tile_cyclic_assignment_is_a_balanced_partition():
     assert [len(s) for s in shards] == [80000] * 8
 
 
+def test_frame_groups_need_equal_ray_shares():
+    """ShardedRenderer(units=U): the frames split into U groups and every rank's share of every group must be the same
+    number of rays (one native call renders them as U equal units); other shapes are refused up front, and the
+    assignment of a shape is computed once."""
+    from ced_nerf_amd import dist as cdist
+    from ced_nerf_amd.dist import ShardedRenderer
+    fn = lambda o, d, ts: (torch.zeros(o.shape[0], 3), torch.zeros(o.shape[0], 1), torch.zeros(o.shape[0], 1), 0)
+    rays = lambda F, H, W: (torch.zeros(F, H, W, 3), torch.ones(F, H, W, 3))
+    r = ShardedRenderer(None, None, 1, 0, "cpu", render_fn=fn, units=2)
+    with pytest.raises(ValueError):
+        r.set_rays(*rays(3, 16, 16))                       # 3 frames do not split into 2 groups
+    r.set_rays(*rays(4, 16, 16))
+    assert r.n_local == 4 * 256
+    two = ShardedRenderer(None, None, 2, 1, "cpu", render_fn=fn, units=2)
+    two.set_rays(*rays(4, 16, 16))                         # 4 tiles per frame, 2 ranks: equal shares
+    assert two.n_local == two.n_pad == 2 * 256
+    odd = ShardedRenderer(None, None, 2, 0, "cpu", render_fn=fn, units=3)
+    with pytest.raises(ValueError):
+        odd.set_rays(*rays(3, 8, 24))                      # 3 tiles per frame over 2 ranks: uneven shares per group
+    with pytest.raises(AssertionError):
+        ShardedRenderer(None, None, 1, 0, "cpu", render_fn=fn, units=9)
+    a = cdist.tile_cyclic_assignment(4, 16, 16, 2)
+    assert cdist.tile_cyclic_assignment(4, 16, 16, 2) is a          # cached per shape
+
+
 def test_sharded_render_world2_gloo_matches_single_process(tmp_path):
     port = _free_port()
     mp.spawn(_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
