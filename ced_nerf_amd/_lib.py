@@ -99,18 +99,55 @@ PROTOTYPES = {
 }
 
 
-def build(force: bool = False, verbose: bool = False) -> str:
+def _includes(path: str, seen=None) -> List[str]:
+    """Transitive closure of the quoted #include files of a source (its rebuild dependencies)."""
+    import re
+    seen = set() if seen is None else seen
+    if path in seen or not os.path.exists(path):
+        return []
+    seen.add(path)
+    out = [path]
+    for inc in re.findall(r'^\s*#\s*include\s+"([^"]+)"', open(path).read(), flags=re.M):
+        out += _includes(os.path.normpath(os.path.join(os.path.dirname(path), inc)), seen)
+    return out
+
+
+def build(force: bool = False, verbose: bool = False, extra_flags: Optional[List[str]] = None) -> str:
     """Compile every HIP source for gfx950 into the in-tree shared library (hipcc cross-compiles
-    without a GPU)."""
+    without a GPU).  One object per source, compiled in parallel and re-made only when the source or
+    one of the headers it includes (transitively) is newer; objects live in build/obj (git-ignored)."""
+    from concurrent.futures import ThreadPoolExecutor
     srcs = [os.path.join(_PKG, "csrc", s) for s in SOURCES]
-    deps = srcs + [os.path.join(_PKG, "csrc", h) for h in ("ced_common.hpp", "march_core.hpp", "field_args.hpp", "field_device.hpp")] + [ os.path.join(_ROOT, "include", "cednerf_hip.h")]
-    if not force and os.path.exists(LIB_PATH) and all(os.path.getmtime(LIB_PATH) >= os.path.getmtime(d) for d in deps):
-        return LIB_PATH
     hipcc = os.environ.get("HIPCC", "hipcc")
-    cmd = [hipcc] + HIPCC_FLAGS + ["-o", LIB_PATH] + srcs
-    if verbose:
-        print(" ".join(cmd))
-    subprocess.check_call(cmd)
+    flags = [f for f in HIPCC_FLAGS if f != "-shared"] + list(extra_flags or [])
+    obj_dir = os.path.join(_ROOT, "build", "obj")
+    os.makedirs(obj_dir, exist_ok=True)
+    stamp = os.path.join(obj_dir, "flags.txt")
+    flag_text = " ".join([hipcc] + flags)
+    if not os.path.exists(stamp) or open(stamp).read() != flag_text:
+        force = True
+    jobs, objs = [], []
+    for src in srcs:
+        obj = os.path.join(obj_dir, os.path.basename(src) + ".o")
+        objs.append(obj)
+        deps = _includes(src)
+        if force or not os.path.exists(obj) or any(os.path.getmtime(obj) < os.path.getmtime(d) for d in deps):
+            jobs.append([hipcc] + flags + ["-c", src, "-o", obj])
+    if not jobs and os.path.exists(LIB_PATH) and all(os.path.getmtime(LIB_PATH) >= os.path.getmtime(o) for o in objs):
+        return LIB_PATH
+
+    def run(cmd):
+        if verbose:
+            print(" ".join(cmd), flush=True)
+        subprocess.check_call(cmd)
+
+    workers = max(1, min(len(jobs), int(os.environ.get("CED_BUILD_JOBS", str(min(os.cpu_count() or 1, 8))))))
+    if jobs:
+        with ThreadPoolExecutor(max_workers=workers) as pool:
+            list(pool.map(run, jobs))
+    run([hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB_PATH] + objs)
+    with open(stamp, "w") as f:
+        f.write(flag_text)
     return LIB_PATH
 
 

@@ -248,8 +248,10 @@ class PipelinedRenderer:
             futures = [self.pool.submit(self._lane, i, timestamps) for i in range(len(self.lanes))]
             locals_ = [f.result() for f in futures]
             if main is not None and not self.async_gather:
-                for s in self.streams:
+                for s, loc in zip(self.streams, locals_):
                     main.wait_stream(s)
+                    for t in loc[:3]:
+                        t.record_stream(main)           # produced on the lane's stream, consumed on the caller's
         if not self.async_gather or self.streams[0] is None:
             return [lane.gather(loc) for lane, loc in zip(self.lanes, locals_)]
         if self.comm_stream is None:
@@ -323,6 +325,8 @@ class PipelinedRenderer:
                 else:
                     if main is not None:
                         main.wait_stream(self.streams[i])
+                        for t in loc[:3]:
+                            t.record_stream(main)
                     row.append(lane.gather(loc))
             outs.append(row)
         for t in threads:

@@ -71,8 +71,9 @@ class DNGPradianceField(torch.nn.Module):
             raise NotImplementedError("hash4motion is never enabled by the reference (train_real.py:263)")
         if not time_inject_before_sigma:
             raise NotImplementedError("time_inject_before_sigma=False is never used by the reference")
-        if use_feat_predict or use_weight_predict:
-            raise NotImplementedError("feature/weight prediction heads are training-only (cednerf/model.py:428-443)")
+        # use_feat_predict / use_weight_predict (run_hyper.sh:1 passes -f): the two heads only run under
+        # `return_interal=self.training` (cednerf/model.py:428-443,479-484), i.e. they are inert in the eval path
+        # this module implements; the flags are accepted and recorded, training with them is `train.TrainableField`.
         self.num_dim = num_dim
         self.use_viewdirs = use_viewdirs
         self.geo_feat_dim = geo_feat_dim
@@ -209,8 +210,9 @@ class DNGPradianceField(torch.nn.Module):
     @torch.no_grad()
     def query_density(self, x, t, return_feat: bool = False, return_interal: bool = False):
         """cednerf/model.py:367-445 (eval: no training-only `interal_output`)."""
-        if return_interal and self.training:
-            raise NotImplementedError("training-time internal outputs are not part of the rendering hot path")
+        if return_interal and self.training and (self.use_feat_predict or self.use_weight_predict):
+            raise NotImplementedError("the feature/weight prediction heads (cednerf/model.py:428-443) run in training "
+                                      "only; this module is the eval path")
         shp = x.shape
         _, sigma, geo = ops.field_forward(self._descriptor(), x.reshape(-1, 3).float().contiguous(),
                                           t.reshape(-1).float().contiguous(), None, want_geo=return_feat)

@@ -27,11 +27,21 @@ def _chk(t: Optional[torch.Tensor], dtype: torch.dtype, name: str, allow_none: b
         raise ValueError(f"{name} is required")
     if not t.is_cuda:
         raise NotImplementedError(f"Only support cuda inputs ({name} is on {t.device}).")
+    _check_current_device(t.device.index, name)
     if t.dtype != dtype:
         raise TypeError(f"{name} must be {dtype}, got {t.dtype}")
     if not t.is_contiguous():
         raise ValueError(f"{name} must be contiguous")
     return t
+
+
+def _check_current_device(index, name: str) -> None:
+    """The library launches on the CURRENT device and stream (`_stream()`), with raw pointers: a tensor of another
+    device would be dereferenced on the wrong GPU (a memory fault, not an exception).  Refuse instead."""
+    cur = torch.cuda.current_device()
+    if index is not None and index != cur:
+        raise RuntimeError(f"{name} lives on cuda:{index} but the current device is cuda:{cur}: wrap the call in "
+                           f"`with torch.cuda.device({index}):` (the kernels launch on the current device's stream)")
 
 
 def _p(t: Optional[torch.Tensor]) -> C.c_void_p:

@@ -25,6 +25,7 @@ import torch
 from . import ops
 from .hashgrid import level_tables
 from .render import rendering_train
+from .utils import trunc_exp
 
 
 class _HashFn(torch.autograd.Function):
@@ -116,7 +117,7 @@ class TrainableField(torch.nn.Module):
             te = self.time_encoder(tt) if self.time_mode == 1 else self.time_encoder_feat(tt, mn)
             feat = torch.cat([feat, te], dim=-1)
         bout = self._mlp(feat, list(self.mlp_base))
-        sigma = torch.exp(bout[:, 0] - 1.0) * selector.to(bout.dtype)               # trunc_exp(x - 1) * selector
+        sigma = trunc_exp(bout[:, 0] - 1.0) * selector.to(bout.dtype)               # model.py:105,414-417
         d = directions.float()
         u = (d / d.norm(dim=-1, keepdim=True) + 1.0) / 2.0
         w = u * 2.0 - 1.0

@@ -31,9 +31,23 @@ def set_random_seed(seed):
     torch.manual_seed(seed)
 
 
-def trunc_exp(x: torch.Tensor) -> torch.Tensor:
-    """Forward of cednerf/utils.py:27-43 (exp evaluated in float32)."""
-    return torch.exp(x.float())
+class _TruncExp(torch.autograd.Function):
+    """cednerf/utils.py:27-43: exp in float32; the backward multiplies by exp(clamp(x, max=15)) so that large
+    pre-activations give finite gradients."""
+
+    @staticmethod
+    def forward(ctx, x):
+        x = x.float()
+        ctx.save_for_backward(x)
+        return torch.exp(x)
+
+    @staticmethod
+    def backward(ctx, g):
+        (x,) = ctx.saved_tensors
+        return g * torch.exp(torch.clamp(x, max=15))
+
+
+trunc_exp = _TruncExp.apply
 
 
 _EVAL_PASS_RAYS = 1 << 21     # rays per internal eval pass of render_image

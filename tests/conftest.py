@@ -39,6 +39,13 @@ def oracle():
     return O
 
 
+def free_port() -> int:
+    """A TCP port free right now on 127.0.0.1 (rendezvous of the multi-process tests)."""
+    import socket
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); p = s.getsockname()[1]; s.close()
+    return p
+
+
 def bits(a):
     a = np.ascontiguousarray(a)
     if a.dtype == np.float32:

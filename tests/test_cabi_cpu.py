@@ -167,9 +167,66 @@ def test_field_module_construction_and_guards():
         f(torch.zeros(2, 3), torch.zeros(2, 1), torch.ones(2, 3))
     g = DNGPradianceField([-1, -1, -1, 1, 1, 1], dst_resolution=1024, log2_hashmap_size=10, seed=1)
     assert abs(float(g.hash_table.abs().max())) <= 1e-4 and g.mlp_base[0].shape == (64, 32)
-    for bad in (dict(n_levels=8), dict(hash4motion=True), dict(use_feat_predict=True), dict(geo_feat_dim=7)):
+    for bad in (dict(n_levels=8), dict(hash4motion=True), dict(geo_feat_dim=7)):
         with pytest.raises(NotImplementedError):
             DNGPradianceField([-1, -1, -1, 1, 1, 1], log2_hashmap_size=10, **bad)
+    # the published configuration (run_hyper.sh:1: -te -ta -f -ae -df -d) constructs: the prediction heads the -f
+    # flag adds only run in training (cednerf/model.py:428-443), the eval path ignores them
+    h = DNGPradianceField([-1, -1, -1, 1, 1, 1], log2_hashmap_size=10, use_feat_predict=True, use_weight_predict=True,
+                          use_time_embedding=True, use_time_attenuation=True, use_div_offsets=True).eval()
+    assert h.use_feat_predict and h.time_mode == 2 and h.xyz_wrap[3].shape == (6, 64)
+
+
+def test_ops_refuse_tensors_of_another_device(monkeypatch):
+    """The wrappers launch on the current device's stream with raw pointers: a tensor of another GPU is refused
+    before any launch (no GPU needed for the check itself)."""
+    from ced_nerf_amd import ops
+    monkeypatch.setattr(torch.cuda, "current_device", lambda: 0)
+    ops._check_current_device(0, "x")
+    ops._check_current_device(None, "x")
+    with pytest.raises(RuntimeError, match="cuda:1 but the current device is cuda:0"):
+        ops._check_current_device(1, "rays_o")
+
+
+def test_trunc_exp_gradient_is_clamped_like_the_reference():
+    """cednerf/utils.py:27-43: forward exp(x) in float32, backward g * exp(clamp(x, max=15))."""
+    from ced_nerf_amd.utils import trunc_exp
+    x = torch.tensor([-2.0, 0.5, 15.0, 40.0, 100.0], requires_grad=True)
+    y = trunc_exp(x)
+    assert y.dtype == torch.float32 and torch.equal(y.detach(), torch.exp(x.detach()))
+    y.backward(torch.ones_like(y))
+    want = torch.exp(torch.clamp(x.detach(), max=15))
+    assert torch.equal(x.grad, want) and bool(torch.isfinite(x.grad).all())
+    xh = torch.tensor([1.0], dtype=torch.float16, requires_grad=True)
+    assert trunc_exp(xh).dtype == torch.float32
+
+
+def test_state_dict_round_trip_cpu():
+    """SURVEY section 5 checkpoint row (train_real.py:433-441,524-529): {"radiance_field": sd, "occupancy_grid": sd}
+    saved with torch.save and loaded into freshly built modules reproduces every parameter and the estimator keys
+    resolution / aabbs / occs / binaries (the render round trip on the device is in tests/test_gpu_parity.py)."""
+    import io
+    from ced_nerf_amd import synthetic as S
+    from ced_nerf_amd.model import DNGPradianceField
+    from ced_nerf_amd.nerfacc_api import OccGridEstimator
+    sc = S.make_scene("hypernerf", 16, 12, "trained", log2_hashmap_size=10)
+    cfg = sc["cfg"]
+    f = DNGPradianceField.from_params(sc["params"], "cpu")
+    est = OccGridEstimator(cfg["aabb"], cfg["grid_resolution"], cfg["grid_levels"])
+    est.set_binaries(torch.from_numpy(sc["binaries"]))
+    buf = io.BytesIO()
+    torch.save({"radiance_field": f.state_dict(), "occupancy_grid": est.state_dict()}, buf)
+    buf.seek(0)
+    ck = torch.load(buf)
+    assert set(ck["occupancy_grid"]) == {"resolution", "aabbs", "occs", "binaries"}
+    assert {"aabb", "hash_table", "xyz_wrap.0", "xyz_wrap.3", "mlp_base.0", "mlp_base.1", "mlp_head.2"} <= set(ck["radiance_field"])
+    f2 = DNGPradianceField(aabb=cfg["aabb"], dst_resolution=cfg["hash_max_res"], log2_hashmap_size=10,
+                           moving_step=cfg["moving_step"], seed=3, **cfg["flags"])
+    est2 = OccGridEstimator(cfg["aabb"], cfg["grid_resolution"], cfg["grid_levels"])
+    f2.load_state_dict(ck["radiance_field"]); est2.load_state_dict(ck["occupancy_grid"])
+    for (k, a), (_, b) in zip(f.state_dict().items(), f2.state_dict().items()):
+        assert torch.equal(a, b), k
+    assert torch.equal(est2.binaries, est.binaries) and torch.equal(est2.occs, est.occs) and torch.equal(est2.aabbs, est.aabbs)
 
 
 def test_estimator_state_and_api_names():

@@ -8,7 +8,7 @@ import numpy as np
 import pytest
 import torch
 
-from conftest import assert_bitexact
+from conftest import assert_bitexact, free_port
 
 pytestmark = pytest.mark.gpu
 
@@ -784,7 +784,7 @@ def test_sharded_renderer_collective_path_on_gpu(oracle, full_frame):
     created = False
     if not dist.is_initialized():
         import os
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1"); os.environ.setdefault("MASTER_PORT", "29533")
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1"); os.environ.setdefault("MASTER_PORT", str(free_port()))
         dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device(DEV))
         created = True
     try:
@@ -1169,7 +1169,7 @@ def test_bench_two_rank_rehearsal():
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     env = dict(os.environ, CED_BENCH_BACKEND="gloo")
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
-           "--master-port", "29517", os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1",
+           "--master-port", str(free_port()), os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1",
            "--width", "256", "--height", "256", "--no-cpu-baseline", "--also", "f16x2"]
     out = subprocess.run(cmd, cwd=root, env=env, capture_output=True, text=True, timeout=600)
     assert out.returncode == 0, out.stderr[-2000:]
