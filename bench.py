@@ -89,7 +89,28 @@ def cpu_baseline(sc, args):
             "rays_per_sec": o.shape[0] * o.shape[1] / dt,
             "sample": f"{args.cpu_passes} passes over every {s}th pixel in x and y of the same "
                       f"{args.width}x{args.height} frame ({o.shape[0] * o.shape[1]} rays, {out[3]} samples, "
-                      f"{dt:.1f} s per pass)"}
+                      f"{dt:.1f} s per pass)"}, out
+
+
+def parity_vs_oracle(oracle_out, gpu_single, gpu_timed_frame0, mode):
+    """Frame 0 of the timed set against the pixels the cpu_baseline pass of the oracle computed for the same rays
+    (the oracle is the checker here, never the thing measured).  gpu_single: (rgb, opacity, depth, total) of
+    render_image_test on that frame alone; gpu_timed_frame0: the same frame as the timed pipeline produced it."""
+    w_rgb, w_op, w_dp, w_total = oracle_out[:4]
+    g = [t.detach().cpu().numpy() for t in gpu_single[:3]]
+    want = [w_rgb, w_op, w_dp]
+    diffs = [float(np.abs(a.reshape(b.shape).astype(np.float64) - b).max()) for a, b in zip(g, want)]
+    bitexact = all(np.array_equal(a.reshape(b.shape).view(np.uint32), np.ascontiguousarray(b).view(np.uint32))
+                   for a, b in zip(g, want))
+    mse = float(np.mean((g[0].reshape(w_rgb.shape).astype(np.float64) - w_rgb) ** 2))
+    out = {"frame": 0, "mlp_precision": mode, "rgb_max_abs": diffs[0], "opacity_max_abs": diffs[1],
+           "depth_max_abs": diffs[2], "samples_gpu": int(gpu_single[3]), "samples_oracle": int(w_total),
+           "samples_equal": int(gpu_single[3]) == int(w_total), "bitexact": bool(bitexact),
+           "psnr_db": None if mse == 0.0 else float(-10.0 * np.log10(mse))}
+    if gpu_timed_frame0 is not None:
+        out["timed_frame_equals_single_render"] = all(
+            bool(torch.equal(a.reshape(b.shape), b)) for a, b in zip(gpu_timed_frame0, gpu_single[:3]))
+    return out
 
 
 def cpu_baseline_pytorch(sc, args):
@@ -209,6 +230,7 @@ def main():
     ref_event.record()
     t0 = time.perf_counter()
     samples_local = 0
+    last_row = None
     if os.environ.get("CED_BENCH_JOIN_STEPS", "0") != "0":
         for _ in range(args.steps):
             out = step()
@@ -221,6 +243,8 @@ def main():
             lane_renderers[l].tracer = tracers[l][s_] if s_ < len(tracers[l]) else None
         rows = renderer.render_steps(ts, args.steps, before_frame=before_frame)
         samples_local = sum(o["local_samples"] for row in rows for o in row)
+        last_row = rows[-1]
+        del rows
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
@@ -392,7 +416,20 @@ def main():
             v_["parity"] = notes[k_]
         line["other_mlp_precisions"] = others
     if not args.no_cpu_baseline:
-        line["cpu_baseline"] = cpu_baseline(sc, args)
+        line["cpu_baseline"], oracle_out = cpu_baseline(sc, args)
+        if world == 1 and args.cpu_stride == 1:
+            # parity of the benchmarked workload: frame 0 (the scene's own camera) rendered alone by the HIP path in
+            # the timed arithmetic mode, against the oracle's pixels of the same rays; and the frame as the timed
+            # pipeline (frames in flight, several frames per call) produced it against that single render
+            from ced_nerf_amd.utils import render_image_test
+            single = render_image_test(args.max_samples, field, est, Rays(T(sc["origins"]), T(sc["viewdirs"])),
+                                       timestamps=ts, **rk)
+            timed0 = None
+            if last_row is not None:
+                o0 = last_row[0]
+                timed0 = (o0["rgb"][0], o0["opacity"][0], o0["depth"][0])
+            torch.cuda.synchronize()
+            line["parity_vs_oracle"] = parity_vs_oracle(oracle_out, single, timed0, args.mlp_precision)
         if args.torch_stride > 0:
             line["cpu_baseline_pytorch"] = cpu_baseline_pytorch(sc, args)
     print(json.dumps(line))

@@ -1,0 +1,126 @@
+"""Full-size, full-frame parity: the workloads bench.py times and BASELINE.json names, rendered by the HIP
+`render_image_test` (cednerf/utils.py:153-318, image-global N_samples schedule) and by the CPU oracle on the same
+rays -- not a subset, not a self-comparison.
+
+  C2  D-NeRF 800x800, fp32 table, exact MLPs            schedule + counts + pixels bit-exact
+  C3  HyperNeRF 536x960, -te -ta -df, 2 levels, cone     same
+  C4  DyNeRF 1352x1014, 4 levels (one GPU's view)        same
+  C5x D-NeRF 800x800, fp16 hash features, exact MLPs     same (the fp16 table is exact arithmetic on rounded data)
+  C5  D-NeRF 800x800, fp16 features + fp16 MFMA MLPs     against the oracle's fp16-operand mode: error quantiles
+  C2h the same frame with split-fp16 MLPs (f16x2)        against the plain oracle: north-star 1e-4, error quantiles
+
+The oracle renders a frame in 5-15 s on the GPU box's host cores (OpenMP).  Tolerances of the two half-precision
+rows are quantile bounds: a wrong layer, a swapped feature or a dropped level moves the MEDIAN
+pixel by >1e-2, so p50 / p99 / p99.9 / mean bounds a few times above the measured figures catch it, which a
+max-abs bound wide enough for the rare early-stop flip does not.
+"""
+import numpy as np
+import pytest
+import torch
+
+from conftest import assert_bitexact
+
+pytestmark = pytest.mark.gpu
+
+DEV = "cuda:0"
+
+
+def T(a):
+    return torch.from_numpy(np.ascontiguousarray(a)).to(DEV)
+
+
+def N(t):
+    return t.detach().cpu().numpy()
+
+
+def _setup(oracle, name, w, h, prec, mlp_half=False, **kw):
+    from ced_nerf_amd import synthetic as S
+    from ced_nerf_amd.model import DNGPradianceField
+    from ced_nerf_amd.nerfacc_api import OccGridEstimator
+    from ced_nerf_amd.utils import Rays
+    sc = S.make_scene(name, w, h, "trained", **kw)
+    cfg = sc["cfg"]
+    of = oracle.OracleField(sc["params"], mlp_half=mlp_half)
+    oest = oracle.OracleEstimator(cfg["aabb"], cfg["grid_resolution"], cfg["grid_levels"], sc["binaries"])
+    f = DNGPradianceField.from_params(sc["params"], DEV, mlp_precision=prec).eval()
+    est = OccGridEstimator(cfg["aabb"], cfg["grid_resolution"], cfg["grid_levels"]).to(DEV)
+    est.set_binaries(T(sc["binaries"]))
+    rays = Rays(origins=T(sc["origins"]), viewdirs=T(sc["viewdirs"]))
+    rk = dict(sc["render"]); rk["render_bkgd"] = T(rk["render_bkgd"])
+    return sc, of, oest, f, est, rays, rk
+
+
+EXACT = [
+    ("C2", "dnerf", 800, 800, {}),
+    ("C3", "hypernerf", 536, 960, {}),
+    ("C4", "dynerf", 1352, 1014, {}),
+    ("C5x", "dnerf", 800, 800, {"table_dtype": np.float16}),
+]
+
+
+@pytest.mark.parametrize("tag,name,w,h,kw", EXACT, ids=[c[0] for c in EXACT])
+def test_full_frame_render_image_test_bitexact(oracle, tag, name, w, h, kw):
+    from ced_nerf_amd import ops
+    from ced_nerf_amd.utils import render_image_test
+    sc, of, oest, f, est, rays, rk = _setup(oracle, name, w, h, "f32", **kw)
+    trace = []
+    w_rgb, w_op, w_dp, w_total = oracle.render_image_test(1024, of, oest, sc["origins"], sc["viewdirs"],
+                                                          timestamps=sc["timestamps"], trace=trace, **sc["render"])
+    tracer = ops.FrameTracer(capacity=1100, with_events=False)
+    rgb, op, dp, total = render_image_test(1024, f, est, rays, timestamps=T(sc["timestamps"]), tracer=tracer, **rk)
+    its = tracer.iterations()
+    print(f"[{tag}] {w}x{h}: {total} samples in {len(its)} iterations (oracle {w_total} in {len(trace)})")
+    assert total == w_total and total > 100000
+    # the image-global schedule of every iteration: rays alive, samples per ray, samples marched
+    assert its == [dict(n_alive=t["n_alive"], n_samples=t["n_samples"], n_new=t["n_new"]) for t in trace]
+    assert rgb.shape == (h, w, 3) and op.shape == (h, w, 1) and dp.shape == (h, w, 1)
+    assert_bitexact(N(rgb), w_rgb, f"{tag} rgb")
+    assert_bitexact(N(dp), w_dp, f"{tag} depth")
+    assert_bitexact(N(op), w_op, f"{tag} opacity")
+
+
+def _quantiles(err):
+    e = np.asarray(err, np.float64).reshape(-1)
+    return dict(p50=float(np.quantile(e, 0.5)), p99=float(np.quantile(e, 0.99)), p999=float(np.quantile(e, 0.999)),
+                mean=float(e.mean()), max=float(e.max()))
+
+
+# bounds = measured on MI355X (printed by the test) x ~3; see DESIGN.md section 2
+HALF_FRAME_BOUNDS = {
+    # f16x2 against the plain fp32 oracle: the north-star tolerance itself on the maximum, and the bulk far below it
+    # (measured r02: rgb p99 4.8e-7, p99.9 8.9e-7, mean 1.7e-7, max 4.6e-5; same sample count)
+    "C2h": dict(rgb=dict(p50=5e-7, p99=2e-6, p999=4e-6, mean=6e-7, max=1e-4),
+                depth=dict(p50=2e-7, p99=4e-6, p999=6e-6, mean=8e-7, max=1e-4),
+                opacity=dict(p50=2e-7, p99=2e-6, p999=4e-6, mean=1.5e-7, max=1e-4), samples_rel=1e-5),
+    # f16 + fp16 table against the oracle's fp16-operand mode (differs in fp32 summation order only)
+    # (measured r02: rgb p99 2.8e-5, p99.9 1.4e-4, mean 1.2e-6, max 7.4e-4; 19 samples of 4.67 M differ)
+    "C5": dict(rgb=dict(p50=5e-7, p99=1e-4, p999=6e-4, mean=5e-6, max=4e-3),
+               depth=dict(p50=2e-7, p99=5e-6, p999=5e-5, mean=1e-6, max=1e-3),
+               opacity=dict(p50=2e-7, p99=1e-6, p999=2e-5, mean=3e-7, max=4e-3), samples_rel=3e-5),
+}
+
+
+@pytest.mark.parametrize("tag,prec,kw", [("C2h", "f16x2", {}), ("C5", "f16", {"table_dtype": np.float16})])
+def test_full_frame_half_precision_quantiles(oracle, tag, prec, kw):
+    from ced_nerf_amd.utils import render_image_test
+    sc, of, oest, f, est, rays, rk = _setup(oracle, "dnerf", 800, 800, prec, mlp_half=(prec == "f16"), **kw)
+    w_rgb, w_op, w_dp, w_total = oracle.render_image_test(1024, of, oest, sc["origins"], sc["viewdirs"],
+                                                          timestamps=sc["timestamps"], **sc["render"])
+    rgb, op, dp, total = render_image_test(1024, f, est, rays, timestamps=T(sc["timestamps"]), **rk)
+    B = HALF_FRAME_BOUNDS[tag]
+    rel = abs(total - w_total) / w_total
+    print(f"[{tag} {prec}] samples {total} vs {w_total} (rel {rel:.2e})")
+    assert rel <= B["samples_rel"]
+    hit = w_op.reshape(-1) > 0                                # pixels whose ray met anything (the others are exact)
+    for nm, got, want in (("rgb", N(rgb), w_rgb), ("depth", N(dp), w_dp), ("opacity", N(op), w_op)):
+        err = np.abs(got - want).reshape(hit.shape[0], -1).max(axis=1)
+        assert np.all(err[~hit] == 0), f"{tag} {nm}: pixels of rays that miss everything must be exact"
+        q = _quantiles(err[hit])
+        print(f"[{tag} {prec}] {nm}: " + " ".join(f"{k} {v:.2e}" for k, v in q.items()))
+        for k, bound in B[nm].items():
+            assert q[k] <= bound, f"{tag} {nm} {k}: {q[k]:.3e} > {bound:.1e}"
+    # PSNR of the frame against the oracle's (train_real.py:494-495): the metric's "PSNR vs ref"
+    mse = float(np.mean((N(rgb).astype(np.float64) - w_rgb) ** 2))
+    psnr = -10.0 * np.log10(max(mse, 1e-30))
+    print(f"[{tag} {prec}] PSNR vs oracle {psnr:.1f} dB")
+    assert psnr >= (120.0 if prec == "f16x2" else 95.0)        # measured r02: 139.0 / 110.1 dB

@@ -246,14 +246,27 @@ def test_field_forward(oracle, case, regime):
 #   f16x2: operands carry 22 significant bits -> compared with the plain fp32 oracle.
 #   f16:   operands rounded to fp16 -> compared with the oracle's fp16-operand mode (mlp_half), which differs
 #          from the hardware only in the order of the fp32 accumulation (and the rare fp16 rounding flips it causes).
-# Tolerances = observed maxima on MI355X x ~4 (printed by the test with -s).  "init" = reference initialisation
-# (hash features ~1e-4, i.e. fp16 subnormals: relative precision drops there); "trained" = the amplified regime of
-# synthetic.init_field_params (density row x32, head output x16, sigma up to 1e14), where one fp16 rounding step is
-# magnified ~100x: max is therefore checked loosely and the mean tightly.
-HALF_TOL = {            # prec, regime -> (rgb max abs, rgb mean abs, density max rel, base_mlp_out max / scale)
-    ("f16x2", "init"): (2e-5, 2e-6, 5e-5, 4e-3), ("f16x2", "trained"): (4e-4, 2e-5, 6e-3, 4e-4),
-    ("f16", "init"): (2e-4, 2e-5, 5e-4, 1e-3), ("f16", "trained"): (5e-1, 1e-3, 5e-1, 5e-3),
+# Tolerances are QUANTILE bounds (p99, p99.9, mean, max) = the figures measured on MI355X (printed by the test with -s;
+# r02: gpurun_out/r2a/half.log) x 3-4.  "init" = reference initialisation (hash features ~1e-4: the fp16 remainders of
+# f16x2 are subnormal there, hence the larger relative geo error); "trained" = the amplified regime of
+# synthetic.init_field_params (density row x32, head output x16), where one fp16 rounding step is magnified ~100x.  A
+# wrong layer, feature order or level moves the MEDIAN by >1e-2, i.e. fails every column; the max column only has to
+# admit the rare rounding flip.
+HALF_Q = {      # (prec, regime) -> {quantity: (p99, p999, mean, max)}; rgb abs, density relative, base_mlp_out / scale
+    ("f16x2", "init"): dict(rgb=(3e-7, 5e-7, 1e-7, 1e-6), sig=(1e-6, 1.5e-6, 3e-7, 2e-6), geo=(2.5e-3, 3e-3, 1.5e-3, 4e-3)),
+    ("f16x2", "trained"): dict(rgb=(4e-5, 1.2e-4, 2e-6, 4e-4), sig=(8e-4, 2e-3, 3e-5, 6e-3), geo=(5e-5, 1.2e-4, 2e-6, 4e-4)),
+    ("f16", "init"): dict(rgb=(1.2e-5, 6e-5, 5e-7, 2e-4), sig=(1e-6, 1e-4, 5e-7, 5e-4), geo=(1e-6, 4e-4, 1.5e-6, 1e-3)),
+    ("f16", "trained"): dict(rgb=(9e-4, 2e-3, 3e-5, 5e-3), sig=(6e-3, 3e-2, 2.5e-4, 8e-2), geo=(5e-4, 1.8e-3, 1.5e-5, 4e-3)),
 }
+HALF_TOL = {k: (v["rgb"][3], v["rgb"][2], v["sig"][3], v["geo"][3]) for k, v in HALF_Q.items()}   # (max, mean, max, max)
+
+
+def _check_quantiles(err, bounds, what):
+    e = np.asarray(err, np.float64).reshape(-1)
+    got = (np.quantile(e, 0.99), np.quantile(e, 0.999), e.mean(), e.max())
+    print(f"  QSTAT {what}: p50 {np.quantile(e, .5):.2e} p99 {got[0]:.2e} p999 {got[1]:.2e} mean {got[2]:.2e} max {got[3]:.2e}")
+    for nm, g, b in zip(("p99", "p99.9", "mean", "max"), got, bounds):
+        assert g <= b, f"{what}: {nm} {g:.3e} > {b:.1e}"
 
 
 @pytest.mark.parametrize("case", range(len(FIELD_CASES)))
@@ -275,22 +288,18 @@ def test_field_forward_half_precision(oracle, prec, case, regime):
     want = of.forward(pos, t, d, want_geo=True)
     f = DNGPradianceField.from_params(p, DEV, mlp_precision=prec).eval()
     rgb, res = f(T(pos), T(t), T(d))
-    tol_rgb, tol_rgb_mean, tol_sig, tol_geo = HALF_TOL[(prec, regime)]
+    Q = HALF_Q[(prec, regime)]
     got_sig = N(res["density"])[:, 0]
     # the selector (inside-the-box test) is computed from fp32 positions: identical zero pattern
-    moved = np.abs(N(rgb) - want["rgb"]).max()
-    mean_moved = np.abs(N(rgb) - want["rgb"]).mean()
-    assert moved <= tol_rgb, f"rgb: max abs diff {moved:.3e} > {tol_rgb}"
-    assert mean_moved <= tol_rgb_mean, f"rgb: mean abs diff {mean_moved:.3e} > {tol_rgb_mean}"
     zero_mismatch = int(((got_sig == 0) != (want["density"] == 0)).sum())
     assert zero_mismatch <= 2, f"selector pattern differs on {zero_mismatch} samples"
     both = (got_sig != 0) & (want["density"] != 0)
     rel = np.abs(got_sig[both] - want["density"][both]) / want["density"][both]
-    assert rel.max() <= tol_sig, f"density: max rel diff {rel.max():.3e} > {tol_sig}"
     geo_scale = np.abs(want["base_mlp_out"]).max()
-    dgeo = np.abs(N(res["base_mlp_out"]) - want["base_mlp_out"]).max() / geo_scale
-    assert dgeo <= tol_geo, f"base_mlp_out: max diff {dgeo:.3e} of scale > {tol_geo}"
-    print(f"[{prec} case {case} {regime}] rgb max {moved:.2e} mean {mean_moved:.2e} density rel {rel.max():.2e} geo {dgeo:.2e}")
+    tag = f"field {prec} {regime} case{case}"
+    _check_quantiles(np.abs(N(rgb) - want["rgb"]).max(axis=1), Q["rgb"], tag + " rgb")
+    _check_quantiles(rel, Q["sig"], tag + " density(rel)")
+    _check_quantiles(np.abs(N(res["base_mlp_out"]) - want["base_mlp_out"]).max(axis=1) / geo_scale, Q["geo"], tag + " geo")
 
 
 def test_field_forward_large_persistent_launch(oracle):
@@ -329,17 +338,11 @@ def test_field_forward_large_persistent_launch(oracle):
             assert_bitexact(got_sig, want["density"], "density (large launch)")
             assert_bitexact(got_rgb, want["rgb"], "rgb (large launch)")
         else:
-            tol_rgb, tol_rgb_mean, tol_sig, _ = HALF_TOL[(prec, "trained")]
-            err = np.abs(got_rgb - want["rgb"]).max(axis=1)
-            print(f"[large launch {prec}] rgb max {err.max():.2e} mean {err.mean():.2e} p99.9 {np.quantile(err, 0.999):.2e}")
-            assert err.max() <= tol_rgb
-            assert err.mean() <= tol_rgb_mean
-            assert np.quantile(err, 0.999) <= 30 * tol_rgb_mean
+            Q = HALF_Q[(prec, "trained")]
+            _check_quantiles(np.abs(got_rgb - want["rgb"]).max(axis=1), Q["rgb"], f"large launch {prec} rgb")
             both = (got_sig != 0) & (want["density"] != 0)
             rel = np.abs(got_sig[both] - want["density"][both]) / want["density"][both]
-            print(f"[large launch {prec}] density rel max {rel.max():.2e} mean {rel.mean():.2e}")
-            # f16: a single fp16 rounding flip moves the x32-amplified raw density by O(1): bound the bulk, not the tail
-            assert (rel.max() <= tol_sig) if prec == "f16x2" else (np.quantile(rel, 0.999) <= 5e-2 and rel.mean() <= 2e-3)
+            _check_quantiles(rel, Q["sig"], f"large launch {prec} density(rel)")
             assert int(((got_sig == 0) != (want["density"] == 0)).sum()) <= 2
 
 
@@ -621,15 +624,14 @@ def test_render_image_test_half_precision(oracle, prec, name, wh, kw):
     w_rgb, w_op, w_dp, w_total = oracle.render_image_test(1024, of, oest, sc["origins"], sc["viewdirs"],
                                                           timestamps=sc["timestamps"], **sc["render"])
     rgb, op, dp, total = render_image_test(1024, f, est, rays, timestamps=T(sc["timestamps"]), **rk)
-    d_rgb, d_op, d_dp = np.abs(N(rgb) - w_rgb).max(), np.abs(N(op) - w_op).max(), np.abs(N(dp) - w_dp).max()
-    print(f"[{prec} {name} {kw}] rgb {d_rgb:.2e} opacity {d_op:.2e} depth {d_dp:.2e} samples {total} vs {w_total}")
-    m_rgb = np.abs(N(rgb) - w_rgb).mean()
-    # f16 against the fp16-operand oracle: the two differ in fp32 accumulation order only, but a resulting fp16
-    # rounding flip is amplified by the trained-regime gains -- a loose per-pixel bound and a tight mean
-    tol = 1e-4 if prec == "f16x2" else 5e-2
-    assert d_rgb <= tol and d_op <= tol and d_dp <= tol * 4       # depth is in scene units (up to ~6)
-    assert m_rgb <= (2e-6 if prec == "f16x2" else 1e-4), f"mean rgb diff {m_rgb:.2e}"
-    assert abs(total - w_total) <= max(2, w_total // 500)
+    print(f"[{prec} {name} {kw}] samples {total} vs {w_total}")
+    # (p99, p99.9, mean, max) per pixel; measured r02 (gpurun_out/r2a/half.log) x 3-5.  f16x2: the north-star 1e-4 on
+    # the maximum.  f16 against the fp16-operand oracle: the two differ in fp32 accumulation order only.
+    FQ = {"f16x2": dict(rgb=(2e-6, 4e-6, 2e-7, 1e-4), opacity=(2e-6, 5e-6, 1e-7, 1e-4), depth=(4e-6, 2e-5, 4e-7, 1e-4)),
+          "f16": dict(rgb=(3e-5, 4e-4, 2e-6, 1e-3), opacity=(1e-6, 4e-5, 3e-7, 5e-4), depth=(4e-6, 8e-5, 5e-7, 1e-3))}[prec]
+    for nm, g_, w_ in (("rgb", N(rgb), w_rgb), ("opacity", N(op), w_op), ("depth", N(dp), w_dp)):
+        _check_quantiles(np.abs(g_ - w_).reshape(-1, g_.shape[-1]).max(axis=1), FQ[nm], f"frame {prec} {name} {sorted(kw)} {nm}")
+    assert abs(total - w_total) <= max(2, w_total // 20000)
     if prec == "f16x2":
         assert total == w_total
 
