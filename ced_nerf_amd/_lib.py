@@ -14,7 +14,7 @@ _PKG = os.path.dirname(os.path.abspath(__file__))
 _ROOT = os.path.dirname(_PKG)
 LIB_PATH = os.environ.get("CED_NERF_LIB", os.path.join(_PKG, "libcednerf_hip.so"))
 SOURCES = ["runtime.hip", "march.hip", "composite.hip", "field.hip", "field_half.hip", "frame.hip", "occgrid.hip",
-           "raygen.hip", "wgrad.hip", "pixels.hip"]
+           "raygen.hip", "wgrad.hip", "pixels.hip", "accel.hip"]
 MLP_F32, MLP_F16X2, MLP_F16 = 0, 1, 2          # ced_field_desc.mlp_precision
 MLP_PRECISIONS = {"f32": MLP_F32, "f16x2": MLP_F16X2, "f16": MLP_F16}
 HIPCC_FLAGS = ["--offload-arch=gfx950", "-O3", "-ffp-contract=off", "-fPIC", "-shared", "-std=c++17"]
@@ -66,6 +66,12 @@ PROTOTYPES = {
     "ced_traverse_grids": (C.c_int, [_i64, _vp, _vp, _vp, _i32, _i32, _vp, _vp, _vp, _f, _f, _i32, _vp, _vp, _vp, _vp,
                                      _i32, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "ced_host_skip_march": (_f, [_f, _f, _f, _f]),
+    "ced_occupancy_accel_bytes": (_i64, [_i32, _i32]),
+    "ced_build_occupancy_accel": (C.c_int, [_vp, _i32, _i32, _vp, _i64, _vp]),
+    "ced_host_build_occupancy_accel": (C.c_int, [_vp, _i32, _i32, _vp]),
+    "ced_host_count_steps": (_i32, [C.POINTER(C.c_float), _f, _f, _i32, C.POINTER(C.c_float)]),
+    "ced_host_march_frame": (C.c_int, [_i64, _vp, _vp, _vp, _i32, _i32, _vp, _vp, _f, _f, _f, _i32, _vp, _vp, _vp, _vp, _i32,
+                                       _vp, _vp, _vp, _vp]),
     "ced_hash_encode": (C.c_int, [C.POINTER(HashDesc), _i64, _vp, _vp, _vp, _vp]),
     "ced_hash_encode_backward": (C.c_int, [C.POINTER(HashDesc), _i64, _vp, _vp, _vp, _vp, _i32, _vp]),
     "ced_field_forward": (C.c_int, [C.POINTER(FieldDesc), _i64, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),

@@ -147,6 +147,30 @@ int ced_traverse_grids(int64_t n_rays, const float *rays_o, const float *rays_d,
                        int64_t *counts, float *t_starts, float *t_ends, int64_t *ray_indices,
                        float *termination_planes, int64_t *packed_info_out, void *stream);
 
+/* ---- occupancy acceleration structure of the frame renderer ----
+ * A per-brick (8^3 cells) Chebyshev distance field over `binaries`: the frame renderer's marching sphere-traces it
+ * through empty space and re-enters the exact cell walk in closed form (csrc/march_accel.hpp), so the emitted samples
+ * are those of nerfacc.traverse_grids (cednerf/utils.py:241-264) bit for bit.  Build it once per occupancy-grid update
+ * (train_real.py:332-336) and hand it to ced_render_image_test / ced_render_frames_test; NULL there = built per call.
+ * accel: device memory of ced_occupancy_accel_bytes(n_grids, res) bytes. */
+int64_t ced_occupancy_accel_bytes(int32_t n_grids, int32_t res);
+int ced_build_occupancy_accel(const uint8_t *binaries, int32_t n_grids, int32_t res, void *accel, int64_t accel_bytes,
+                              void *stream);
+
+/* HOST functions (validation aids, no GPU needed): the distance field built on the host (dist_host: n_grids * nb^3
+ * bytes, nb = ceil(res / 8)); the closed-form DDA re-entry  k = 0; while (k < kcap && *x < tau) { *prev = *x; *x += d; ++k; }
+ * and the frame renderer's marching of n_rays rays with the SAME code the device runs (march_accel.hpp is host +
+ * device): counts[r] samples (<= limit) at t_starts/t_ends[r * limit + i]; t_term[r] is the termination plane when
+ * counts[r] == limit (unspecified otherwise: such a ray is dead, cednerf/utils.py:303-306).  dist may be NULL
+ * (plain cell-by-cell walk).  All pointers are host pointers. */
+int ced_host_build_occupancy_accel(const uint8_t *binaries_host, int32_t n_grids, int32_t res, uint8_t *dist_host);
+int32_t ced_host_count_steps(float *x, float d, float tau, int32_t kcap, float *prev);
+int ced_host_march_frame(int64_t n_rays, const float *rays_o, const float *rays_d, const uint8_t *binaries,
+                         int32_t n_grids, int32_t res, const float *aabbs, const float *near_planes, float far_plane,
+                         float step_size, float cone_angle, int32_t limit, const float *t_sorted,
+                         const int64_t *t_indices, const uint8_t *hits, const uint8_t *dist, int32_t start_coarse,
+                         int32_t *counts, float *t_starts, float *t_ends, float *t_term);
+
 /* HOST function (validation aid): the kernels' empty-space skip -- advance t_last by whole steps
  * dt = clamp(t*cone_angle, step_size, 1e10) until t_last + dt/2 >= target -- evaluated on the host
  * with the same code the device runs (closed form when cone_angle == 0). */

@@ -1,0 +1,181 @@
+"""CPU suite: the frame renderer's marching (csrc/march_accel.hpp -- host + device code) run ON THE HOST against the
+oracle's cell-by-cell restatement of nerfacc.traverse_grids (call site cednerf/utils.py:241-264).
+
+The marching sphere-traces a brick distance field through empty space and re-enters the exact DDA in closed form;
+what it must reproduce bit for bit: every emitted (t_start, t_end), every count, and the termination plane of every
+ray that used its whole budget (the rays that stay alive, utils.py:301-306)."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+from conftest import assert_bitexact
+
+
+def P(a):
+    return a.ctypes.data_as(C.c_void_p)
+
+
+@pytest.fixture(scope="module")
+def hip():
+    from ced_nerf_amd import _lib
+    return _lib.lib()
+
+
+def _naive_count(x, d, tau, kcap):
+    x, d, tau = np.float32(x), np.float32(d), np.float32(tau)
+    k, prev = 0, np.float32(0)
+    while k < kcap and x < tau:
+        prev = x
+        x = np.float32(x + d)
+        k += 1
+    return k, x, prev
+
+
+def _check_count(hip, x, d, tau, kcap):
+    k0, x0, p0 = _naive_count(x, d, tau, kcap)
+    xx, pp = C.c_float(float(x)), C.c_float(0.0)
+    k1 = hip.ced_host_count_steps(C.byref(xx), float(d), float(tau), int(kcap), C.byref(pp))
+    assert k1 == k0, (x, d, tau, kcap, k0, k1)
+    assert np.float32(xx.value).view(np.uint32) == np.float32(x0).view(np.uint32), (x, d, tau, kcap, x0, xx.value)
+    if k0 > 0:
+        assert np.float32(pp.value).view(np.uint32) == np.float32(p0).view(np.uint32), (x, d, tau, kcap, p0, pp.value)
+
+
+def test_count_steps_equals_the_float_recurrence(hip):
+    """T(j) = fl(T(j-1) + d): inside a binade the recurrence is an exact arithmetic progression of mantissas; binade
+    crossings, round-half ties, zero and huge increments, tiny and negative starts take real single steps."""
+    rng = np.random.default_rng(0)
+    for _ in range(4000):
+        e = int(rng.integers(-6, 8))
+        x = np.float32(rng.uniform(1, 2) * 2.0 ** e) if rng.random() > 0.05 else np.float32(rng.uniform(-1, 1))
+        d = abs(np.float32(x * 10 ** rng.uniform(-7, 0.5))) if rng.random() > 0.1 else np.float32(rng.uniform(0, 1e-3))
+        tau = np.float32(x + d * rng.uniform(0, 300)) if rng.random() > 0.1 else np.float32(x * rng.uniform(0.5, 40))
+        _check_count(hip, x, d, tau, int(rng.integers(1, 200)))
+    # ties: the increment's remainder is exactly half an ulp of the binade (round-half-even alternates)
+    for e in range(-3, 6):
+        u = np.float32(2.0 ** (e - 23))
+        for q in (0, 1, 5, 1000):
+            d = np.float32((q + 0.5) * float(u))
+            x = np.float32(2.0 ** e * 1.0000001)
+            _check_count(hip, x, d, np.float32(2.0 ** (e + 2)), 150)
+    # degenerate increments and targets
+    for x, d, tau, kcap in ((1.0, 0.0, 2.0, 40), (1.0, np.inf, 2.0, 40), (1.0, 1e-3, np.inf, 100), (1.0, 1e-3, np.nan, 10),
+                            (np.nan, 1e-3, 2.0, 10), (3.0, 1e-3, 2.0, 10), (0.0, 1e-7, 1e-5, 120), (-0.5, 0.01, 0.3, 90),
+                            (1.9999999, 1e-7, 2.0000005, 50), (16777215.0, 1.0, 16777230.0, 20)):
+        _check_count(hip, x, d, tau, kcap)
+
+
+def _march_case(hip, oracle, sc, limit, near, start_coarse, use_dist=True):
+    cfg, rk = sc["cfg"], sc["render"]
+    o = np.ascontiguousarray(sc["origins"].reshape(-1, 3)); d = np.ascontiguousarray(sc["viewdirs"].reshape(-1, 3))
+    n = o.shape[0]
+    binaries = np.ascontiguousarray(sc["binaries"]).astype(np.uint8)
+    m, res = binaries.shape[0], binaries.shape[1]
+    aabbs = oracle.make_aabbs(cfg["aabb"], m)
+    tmin, tmax, hits = oracle.ray_aabb_intersect(o, d, aabbs)
+    ts, ti = oracle.sort_intersections(tmin, tmax)
+    far = np.full((n,), rk["far_plane"], np.float32)
+    w = oracle.traverse_grids(o, d, binaries.astype(bool), aabbs, near, far, rk["render_step_size"], rk["cone_angle"], limit,
+                              True, np.ones(n, bool), ts, ti, hits)
+    wc = w["packed_info"][:, 1]
+    nb = (res + 7) // 8
+    dist = np.empty((m, nb, nb, nb), np.uint8)
+    assert hip.ced_host_build_occupancy_accel(P(binaries), m, res, P(dist)) == 0
+    counts = np.empty(n, np.int32); t0 = np.zeros((n, limit), np.float32); t1 = np.zeros((n, limit), np.float32)
+    tt = np.zeros(n, np.float32)
+    hits8 = np.ascontiguousarray(hits.astype(np.uint8)); ts = np.ascontiguousarray(ts, np.float32); ti = np.ascontiguousarray(ti, np.int64)
+    rc = hip.ced_host_march_frame(n, P(o), P(d), P(binaries), m, res, P(aabbs), P(near), float(rk["far_plane"]),
+                                  float(rk["render_step_size"]), float(rk["cone_angle"]), limit, P(ts), P(ti), P(hits8),
+                                  P(dist) if use_dist else None, int(start_coarse), P(counts), P(t0), P(t1), P(tt))
+    assert rc == 0
+    assert_bitexact(counts.astype(np.int64), wc.astype(np.int64), "sample counts")
+    mask = np.arange(limit)[None, :] < counts[:, None]
+    assert_bitexact(t0[mask], w["t_starts"], "t_starts")
+    assert_bitexact(t1[mask], w["t_ends"], "t_ends")
+    full = wc == limit
+    assert_bitexact(tt[full], w["termination_planes"][full], "termination planes of the rays that stay alive")
+    return int(wc.sum()), int(full.sum()), dist
+
+
+@pytest.mark.parametrize("name,wh", [("dnerf", (64, 48)), ("hypernerf", (40, 56)), ("dynerf", (56, 40))])
+def test_march_frame_matches_oracle_on_the_dataset_shaped_scenes(hip, oracle, name, wh):
+    from ced_nerf_amd import synthetic as S
+    sc = S.make_scene(name, wh[0], wh[1], "trained", log2_hashmap_size=10)
+    rng = np.random.default_rng(3)
+    n = wh[0] * wh[1]
+    total = 0
+    for limit in (1, 4, 9, 64):
+        for resume in (False, True):
+            near = np.full((n,), sc["render"]["near_plane"], np.float32)
+            if resume:       # later iterations: every ray resumes at its own termination plane
+                near = (near + rng.uniform(0, 6, size=n)).astype(np.float32)
+            for start_coarse in (True, False):
+                s, full, dist = _march_case(hip, oracle, sc, limit, near, start_coarse)
+                total += s
+    assert total > 20000 and dist.max() >= 4 and dist.min() == 0
+    # without the distance field the same code is the plain cell-by-cell walk
+    _march_case(hip, oracle, sc, 5, np.full((n,), sc["render"]["near_plane"], np.float32), True, use_dist=False)
+
+
+def _fuzz_scene(seed):
+    """Random configurations (the GPU suite's fuzz, tests/test_gpu_parity.py): grid resolution and level count, step
+    size, cone angle, near / far planes, camera inside or outside the box, irregular occupancy with empty levels."""
+    from ced_nerf_amd import synthetic as S
+    rng = np.random.default_rng(5000 + seed)
+    res = int(rng.choice([24, 32, 64, 128]))            # 24: not a multiple of the brick size
+    levels = int(rng.choice([1, 2, 3]))
+    half = float(rng.choice([1.0, 1.5]))
+    cfg = dict(aabb=[-half] * 3 + [half] * 3, near_plane=float(rng.choice([0.0, 0.13])),
+               far_plane=float(rng.choice([1e10, 4.2])), moving_step=1e-4, hash_max_res=512, grid_resolution=res,
+               grid_levels=levels, render_step_size=float(rng.uniform(2e-3, 1.7e-2)), alpha_thre=0.0,
+               cone_angle=float(rng.choice([0.0, 0.0, 0.0037, 0.012])), bkgd=[0.0, 0.0, 0.0], opengl=bool(rng.integers(2)),
+               camera_angle_x=float(rng.uniform(0.5, 1.1)), radius=float(rng.choice([0.6 * half, 1.9 * half, 2.7 * half])),
+               flags=dict())
+    S.CONFIGS["fuzz"] = cfg
+    try:
+        sc = S.make_scene("fuzz", 36, 28, "init", azim_deg=float(rng.uniform(0, 360)), elev_deg=float(rng.uniform(-40, 60)),
+                          seed=seed, log2_hashmap_size=8)
+    finally:
+        del S.CONFIGS["fuzz"]
+    b = sc["binaries"].copy()
+    mode = seed % 4
+    if mode == 0:
+        b |= rng.uniform(size=b.shape) < 0.02            # sparse random cells everywhere: little to skip
+    elif mode == 1:
+        b[:] = False
+        b[:, res // 2, res // 3, res // 4] = True        # a single occupied cell: long empty stretches
+    elif mode == 2:
+        b[-1] = False                                    # an entirely empty level
+    # axis-aligned and zero-component directions among the rays
+    d = sc["viewdirs"]
+    d[0, 0] = [1.0, 0.0, 0.0]; d[0, 1] = [0.0, -1.0, 0.0]; d[0, 2] = [0.0, 0.70710677, 0.70710677]
+    sc["binaries"] = b
+    return sc, rng
+
+
+@pytest.mark.parametrize("seed", range(12))
+def test_march_frame_matches_oracle_on_random_configurations(hip, oracle, seed):
+    sc, rng = _fuzz_scene(seed)
+    n = sc["origins"].shape[0] * sc["origins"].shape[1]
+    for limit in (1, int(rng.integers(2, 40)), 64):
+        near = np.full((n,), sc["render"]["near_plane"], np.float32)
+        if rng.random() < 0.5:
+            near = (near + rng.uniform(0, 3, size=n)).astype(np.float32)
+        _march_case(hip, oracle, sc, limit, near, bool(rng.integers(2)))
+
+
+def test_distance_field_is_the_chebyshev_brick_distance(hip):
+    rng = np.random.default_rng(2)
+    res = 40                                              # 5 bricks per axis
+    b = np.zeros((2, res, res, res), np.uint8)
+    b[0, 3, 17, 39] = 1; b[0, 30, 2, 9] = 1               # bricks (0,2,4) and (3,0,1); level 1 stays empty
+    dist = np.empty((2, 5, 5, 5), np.uint8)
+    assert hip.ced_host_build_occupancy_accel(P(b), 2, res, P(dist)) == 0
+    occ = [(0, 2, 4), (3, 0, 1)]
+    for x in range(5):
+        for y in range(5):
+            for z in range(5):
+                want = min(max(abs(x - a), abs(y - c), abs(z - e)) for a, c, e in occ)
+                assert dist[0, x, y, z] == want
+    assert (dist[1] == 16).all()                          # nothing within reach: the cap + 1 lower bound
