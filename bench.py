@@ -309,7 +309,8 @@ def main():
         return
     n_rays_step = n_frames * args.width * args.height
     # latency of ONE frame rendered alone (no other frame in flight), for reference (field launches on all CUs again)
-    renderer.restore_field_blocks()
+    for r_ in lane_renderers:
+        r_.field_max_workgroups = 0          # one frame alone: field launches on all CUs
     torch.cuda.synchronize()
     t1 = time.perf_counter()
     single_field = {"ms": 0.0, "launches": 0, "units": 0.0}

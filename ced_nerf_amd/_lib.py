@@ -35,7 +35,7 @@ class FieldDesc(C.Structure):
     """ced_field_desc"""
     _fields_ = [
         ("aabb", C.c_float * 6), ("moving_step", C.c_float), ("use_div_offsets", C.c_int32),
-        ("time_mode", C.c_int32), ("mlp_precision", C.c_int32),
+        ("time_mode", C.c_int32), ("mlp_precision", C.c_int32), ("max_workgroups", C.c_int32),
         ("packed_weights", C.c_void_p), ("packed_floats", C.c_uint64),
         ("hash", HashDesc),
     ]
@@ -70,8 +70,8 @@ PROTOTYPES = {
     "ced_build_occupancy_accel": (C.c_int, [_vp, _i32, _i32, _vp, _i64, _vp]),
     "ced_host_build_occupancy_accel": (C.c_int, [_vp, _i32, _i32, _vp]),
     "ced_host_count_steps": (_i32, [C.POINTER(C.c_float), _f, _f, _i32, C.POINTER(C.c_float)]),
-    "ced_host_march_frame": (C.c_int, [_i64, _vp, _vp, _vp, _i32, _i32, _vp, _vp, _f, _f, _f, _i32, _vp, _vp, _vp, _vp, _i32,
-                                       _vp, _vp, _vp, _vp]),
+    "ced_host_march_frame": (C.c_int, [_i64, _vp, _vp, _vp, _i32, _i32, _vp, _vp, _f, _f, _f, _i32, _vp, _vp, _vp, _vp, _i32, _i32,
+                                       _i32, _vp, _vp, _vp, _vp]),
     "ced_hash_encode": (C.c_int, [C.POINTER(HashDesc), _i64, _vp, _vp, _vp, _vp]),
     "ced_hash_encode_backward": (C.c_int, [C.POINTER(HashDesc), _i64, _vp, _vp, _vp, _vp, _i32, _vp]),
     "ced_field_forward": (C.c_int, [C.POINTER(FieldDesc), _i64, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
@@ -95,11 +95,11 @@ PROTOTYPES = {
     "ced_generate_rays_hypercam": (C.c_int, [_i32, _i32, C.POINTER(C.c_float), C.POINTER(C.c_float), _f, _f, _f, _f, _f,
                                              C.POINTER(C.c_float), C.POINTER(C.c_float), _vp, _vp, _vp]),
     "ced_render_image_test_workspace_bytes": (_i64, [_i64, _i32, _i32, _f, _i32]),
-    "ced_render_image_test": (C.c_int, [C.POINTER(FieldDesc), _i64, _vp, _vp, _vp, _i32, _i32, _vp, _f, _f, _f, _f, _f,
+    "ced_render_image_test": (C.c_int, [C.POINTER(FieldDesc), _i64, _vp, _vp, _vp, _i32, _i32, _vp, _vp, _f, _f, _f, _f, _f,
                                         _i32, _vp, _i32, _vp, _vp, _vp, _vp, _vp, _i64, _vp, C.POINTER(_i64),
                                         C.POINTER(FrameTrace), _vp, _vp]),
     "ced_render_frames_test_workspace_bytes": (_i64, [_i32, _i64, _i32, _i32, _f, _i32]),
-    "ced_render_frames_test": (C.c_int, [C.POINTER(FieldDesc), _i32, _i64, _vp, _vp, _vp, _i32, _i32, _vp, _f, _f, _f, _f,
+    "ced_render_frames_test": (C.c_int, [C.POINTER(FieldDesc), _i32, _i64, _vp, _vp, _vp, _i32, _i32, _vp, _vp, _f, _f, _f, _f,
                                          _f, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _vp, C.POINTER(_i64),
                                          C.POINTER(FrameTrace), _vp, _vp]),
 }

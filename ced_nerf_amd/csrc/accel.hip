@@ -3,6 +3,7 @@
 // occupancy-grid update when the caller keeps it (ced_build_occupancy_accel), or inside every render call otherwise.
 // Also the HOST twins used by the CPU test-suite: the same traversal code (march_accel.hpp is host + device) run
 // against the CPU oracle without a GPU.
+#include <algorithm>
 #include <vector>
 
 #include "ced_common.hpp"
@@ -79,7 +80,78 @@ __global__ __launch_bounds__(256) void brick_dist_round_kernel(const uint8_t *__
     dst[idx] = v;
 }
 
-int build_accel(const uint8_t *binaries, int n_grids, int res, uint8_t *dist, uint8_t *scratch, hipStream_t stream)
+constexpr int kCellCap = 15;       // cell distances are exact up to here; farther cells carry the brick bound
+
+// ---- cell-level field: D(x) = min over occupied p of max_a |x_a - p_a|, separable as three min-max passes ----
+// pass z: 1-D distance along z inside every (x, y) column (one thread per column, two sweeps)
+__global__ __launch_bounds__(256) void cell_dist_z_kernel(const uint8_t *__restrict__ binaries, int n_levels, int res,
+                                                          uint8_t *__restrict__ out)
+{
+    const int64_t col = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (col >= (int64_t)n_levels * res * res) return;
+    const uint8_t *g = binaries + col * res;
+    uint8_t *o = out + col * res;
+    int dmin = kCellCap + 1;
+    for (int z = 0; z < res; ++z) {
+        dmin = g[z] ? 0 : min(dmin + 1, kCellCap + 1);
+        o[z] = (uint8_t)dmin;
+    }
+    dmin = kCellCap + 1;
+    for (int z = res - 1; z >= 0; --z) {
+        dmin = g[z] ? 0 : min(dmin + 1, kCellCap + 1);
+        o[z] = (uint8_t)min((int)o[z], dmin);
+    }
+}
+
+// passes y and x: g'(c) = min over |k| <= cap of max(|k|, g(c + k * stride)) along one axis
+__global__ __launch_bounds__(256) void cell_dist_axis_kernel(const uint8_t *__restrict__ src, uint8_t *__restrict__ dst,
+                                                             int n_levels, int res, int axis)
+{
+    const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int64_t n = (int64_t)res * res * res;
+    if (idx >= n * n_levels) return;
+    const int i = (int)(idx % n);
+    const int z = i % res, y = (i / res) % res, x = i / (res * res);
+    const int pos = axis == 0 ? x : y;
+    const int64_t stride = axis == 0 ? (int64_t)res * res : res;
+    int best = src[idx];
+    for (int k = 1; k < best && k <= kCellCap; ++k) {        // a neighbour k away can only help while k < best
+        if (pos - k >= 0) best = min(best, max(k, (int)src[idx - k * stride]));
+        if (pos + k < res) best = min(best, max(k, (int)src[idx + k * stride]));
+    }
+    (void)z;
+    dst[idx] = (uint8_t)best;
+}
+
+// beyond the exact range a cell carries the bound of its brick: (R - 1) * 8 + 1 cells
+__global__ __launch_bounds__(256) void cell_dist_combine_kernel(uint8_t *__restrict__ cdist, const uint8_t *__restrict__ bdist,
+                                                                int n_levels, int res, int nb)
+{
+    const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int64_t n = (int64_t)res * res * res;
+    if (idx >= n * n_levels) return;
+    int v = cdist[idx];
+    if (v > kCellCap) {
+        const int i = (int)(idx % n);
+        const int z = i % res, y = (i / res) % res, x = i / (res * res);
+        const int R = bdist[((idx / n) * nb + (x >> kBrickShift)) * nb * nb + (int64_t)(y >> kBrickShift) * nb + (z >> kBrickShift)];
+        const int bound = R >= 1 ? (R - 1) * kBrick + 1 : 0;
+        v = max(kCellCap + 1, bound);
+        cdist[idx] = (uint8_t)min(v, 255);
+    }
+}
+
+static inline int64_t align256(int64_t x) { return (x + 255) & ~(int64_t)255; }
+
+// layout of the accel buffer: [bdist m*nb^3][brick scratch m*nb^3] pad [cdist m*res^3][cell scratch m*res^3]
+AccelSpec accel_view(const void *accel, int n_grids, int res, bool with_cells)
+{
+    const int nb = (res + kBrick - 1) / kBrick;
+    const uint8_t *base = (const uint8_t *)accel;
+    return AccelSpec{ base, nb, with_cells ? base + align256(2 * (int64_t)n_grids * nb * nb * nb) : nullptr };
+}
+
+int build_brick_accel(const uint8_t *binaries, int n_grids, int res, uint8_t *dist, uint8_t *scratch, hipStream_t stream)
 {
     const int nb = (res + kBrick - 1) / kBrick;
     const int n_bricks = n_grids * nb * nb * nb;
@@ -97,10 +169,26 @@ int build_accel(const uint8_t *binaries, int n_grids, int res, uint8_t *dist, ui
         if (src != dist && hipMemcpyAsync(dist, src, (size_t)n_bricks, hipMemcpyDeviceToDevice, stream) != hipSuccess)
             return check_launch("build_occupancy_accel (copy)");
     }
-    return check_launch("build_occupancy_accel");
+    return check_launch("build_occupancy_accel (bricks)");
 }
 
-static void host_build_accel(const uint8_t *binaries, int n_grids, int res, uint8_t *dist)
+int build_full_accel(const uint8_t *binaries, int n_grids, int res, uint8_t *accel, hipStream_t stream)
+{
+    const int64_t nb = (res + kBrick - 1) / kBrick;
+    const int64_t n_bricks = n_grids * nb * nb * nb, n_cells = (int64_t)n_grids * res * res * res;
+    uint8_t *bdist = accel, *cdist = accel + align256(2 * n_bricks), *cscr = cdist + n_cells;
+    int rc = build_brick_accel(binaries, n_grids, res, bdist, bdist + n_bricks, stream);
+    if (rc) return rc;
+    const dim3 blk(256), grd((unsigned)((n_cells + 255) / 256));
+    hipLaunchKernelGGL(cell_dist_z_kernel, dim3((unsigned)(((int64_t)n_grids * res * res + 255) / 256)), blk, 0, stream, binaries,
+                       n_grids, res, cdist);
+    hipLaunchKernelGGL(cell_dist_axis_kernel, grd, blk, 0, stream, cdist, cscr, n_grids, res, 1);
+    hipLaunchKernelGGL(cell_dist_axis_kernel, grd, blk, 0, stream, cscr, cdist, n_grids, res, 0);
+    hipLaunchKernelGGL(cell_dist_combine_kernel, grd, blk, 0, stream, cdist, bdist, n_grids, res, (int)nb);
+    return check_launch("build_occupancy_accel (cells)");
+}
+
+static void host_build_bricks(const uint8_t *binaries, int n_grids, int res, uint8_t *dist)
 {
     const int nb = (res + kBrick - 1) / kBrick;
     const size_t n = (size_t)nb * nb * nb;
@@ -134,13 +222,58 @@ static void host_build_accel(const uint8_t *binaries, int n_grids, int res, uint
     }
 }
 
+// the same three passes as the device kernels, on the host
+static void host_build_cells(const uint8_t *binaries, int n_grids, int res, const uint8_t *bdist, uint8_t *cdist)
+{
+    const int nb = (res + kBrick - 1) / kBrick;
+    const int64_t n = (int64_t)res * res * res;
+    std::vector<uint8_t> tmp((size_t)n);
+    for (int lvl = 0; lvl < n_grids; ++lvl) {
+        const uint8_t *g = binaries + lvl * n;
+        uint8_t *out = cdist + lvl * n;
+        for (int64_t col = 0; col < (int64_t)res * res; ++col) {
+            int dmin = kCellCap + 1;
+            for (int z = 0; z < res; ++z) { dmin = g[col * res + z] ? 0 : std::min(dmin + 1, kCellCap + 1); out[col * res + z] = (uint8_t)dmin; }
+            dmin = kCellCap + 1;
+            for (int z = res - 1; z >= 0; --z) {
+                dmin = g[col * res + z] ? 0 : std::min(dmin + 1, kCellCap + 1);
+                out[col * res + z] = (uint8_t)std::min((int)out[col * res + z], dmin);
+            }
+        }
+        for (int axis = 1; axis >= 0; --axis) {
+            const int64_t stride = axis == 0 ? (int64_t)res * res : res;
+            for (int64_t i = 0; i < n; ++i) {
+                const int y = (int)((i / res) % res), x = (int)(i / ((int64_t)res * res));
+                const int pos = axis == 0 ? x : y;
+                int best = out[i];
+                for (int k = 1; k < best && k <= kCellCap; ++k) {
+                    if (pos - k >= 0) best = std::min(best, std::max(k, (int)out[i - k * stride]));
+                    if (pos + k < res) best = std::min(best, std::max(k, (int)out[i + k * stride]));
+                }
+                tmp[(size_t)i] = (uint8_t)best;
+            }
+            for (int64_t i = 0; i < n; ++i) out[i] = tmp[(size_t)i];
+        }
+        for (int64_t i = 0; i < n; ++i) {
+            int v = out[i];
+            if (v > kCellCap) {
+                const int z = (int)(i % res), y = (int)((i / res) % res), x = (int)(i / ((int64_t)res * res));
+                const int R = bdist[(((size_t)lvl * nb + (x >> kBrickShift)) * nb + (y >> kBrickShift)) * nb + (z >> kBrickShift)];
+                const int bound = R >= 1 ? (R - 1) * kBrick + 1 : 0;
+                out[i] = (uint8_t)std::min(std::max(kCellCap + 1, bound), 255);
+            }
+        }
+    }
+}
+
 }  // namespace ced
 
 extern "C" int64_t ced_occupancy_accel_bytes(int32_t n_grids, int32_t res)
 {
     if (n_grids < 1 || res < 1 || res > 1024) return -1;
     const int64_t nb = (res + ced::kBrick - 1) / ced::kBrick;
-    return 2 * (int64_t)n_grids * nb * nb * nb;          // the field + one scratch copy (large grids)
+    // brick field + scratch, then cell field + scratch (layout: ced::accel_view)
+    return ced::align256(2 * (int64_t)n_grids * nb * nb * nb) + 2 * (int64_t)n_grids * res * res * res;
 }
 
 extern "C" int ced_build_occupancy_accel(const uint8_t *binaries, int32_t n_grids, int32_t res, void *accel,
@@ -150,15 +283,17 @@ extern "C" int ced_build_occupancy_accel(const uint8_t *binaries, int32_t n_grid
     const int64_t need = ced_occupancy_accel_bytes(n_grids, res);
     CED_REQUIRE(need > 0 && accel_bytes >= need, "build_occupancy_accel: bad sizes (need %lld bytes, got %lld)",
                 (long long)need, (long long)accel_bytes);
-    return ced::build_accel(binaries, n_grids, res, (uint8_t *)accel, (uint8_t *)accel + need / 2, (hipStream_t)stream);
+    return ced::build_full_accel(binaries, n_grids, res, (uint8_t *)accel, (hipStream_t)stream);
 }
 
 // ---- HOST twins (no GPU needed): validation aids of the CPU test-suite --------------------------------------------
 extern "C" int ced_host_build_occupancy_accel(const uint8_t *binaries_host, int32_t n_grids, int32_t res,
-                                              uint8_t *dist_host)
+                                              uint8_t *accel_host)
 {
-    CED_REQUIRE(binaries_host && dist_host && n_grids >= 1 && res >= 1 && res <= 1024, "host_build_occupancy_accel: bad arguments");
-    ced::host_build_accel(binaries_host, n_grids, res, dist_host);
+    CED_REQUIRE(binaries_host && accel_host && n_grids >= 1 && res >= 1 && res <= 1024, "host_build_occupancy_accel: bad arguments");
+    const int64_t nb = (res + ced::kBrick - 1) / ced::kBrick;
+    ced::host_build_bricks(binaries_host, n_grids, res, accel_host);
+    ced::host_build_cells(binaries_host, n_grids, res, accel_host, accel_host + ced::align256(2 * (int64_t)n_grids * nb * nb * nb));
     return CED_OK;
 }
 
@@ -171,21 +306,34 @@ extern "C" int ced_host_march_frame(int64_t n_rays, const float *rays_o, const f
                                     int32_t n_grids, int32_t res, const float *aabbs, const float *near_planes,
                                     float far_plane, float step_size, float cone_angle, int32_t limit,
                                     const float *t_sorted, const int64_t *t_indices, const uint8_t *hits,
-                                    const uint8_t *dist, int32_t start_coarse, int32_t *counts, float *t_starts,
-                                    float *t_ends, float *t_term)
+                                    const uint8_t *accel_host, int32_t accel_mode, int32_t use_lattice, int32_t start_coarse,
+                                    int32_t *counts, float *t_starts, float *t_ends, float *t_term)
 {
     CED_REQUIRE(n_rays >= 0 && n_grids >= 1 && res >= 1 && limit >= 1, "host_march_frame: bad sizes");
     CED_REQUIRE(rays_o && rays_d && binaries && aabbs && near_planes && t_sorted && t_indices && hits && counts &&
                     t_starts && t_ends && t_term, "host_march_frame: null pointer");
-    const ced::GridSpec G{ binaries, aabbs, n_grids, res, step_size, cone_angle, limit, nullptr, 0, 0 };
-    const ced::AccelSpec S{ dist, (res + ced::kBrick - 1) / ced::kBrick };
+    CED_REQUIRE(accel_mode >= 0 && accel_mode <= 2 && (accel_mode == 0 || accel_host), "host_march_frame: accel_mode 0 (none), 1 (bricks), 2 (cells)");
+    // use_lattice: every near plane must be a point of the lattice that starts at near_planes[0] (as in a frame:
+    // the frame's near plane, or termination planes of earlier iterations)
+    float lattice[256];
+    if (use_lattice) ced::build_lattice(near_planes[0], step_size, lattice);
+    const ced::GridSpec G{ binaries, aabbs, n_grids, res, step_size, cone_angle, limit,
+                           (use_lattice && cone_angle == 0.0f && step_size > 0.0f) ? lattice : nullptr };
+    ced::AccelSpec S{ nullptr, (res + ced::kBrick - 1) / ced::kBrick, nullptr };
+    if (accel_mode) S = ced::accel_view(accel_host, n_grids, res, accel_mode == 2);
     for (int64_t r = 0; r < n_rays; ++r) {
         const float o[3] = { rays_o[3 * r], rays_o[3 * r + 1], rays_o[3 * r + 2] };
         const float d[3] = { rays_d[3 * r], rays_d[3 * r + 1], rays_d[3 * r + 2] };
         float *t0 = t_starts + r * limit, *t1 = t_ends + r * limit;
-        counts[r] = ced::traverse_ray_frame(
-            G, S, start_coarse != 0, o, d, near_planes[r], far_plane, t_sorted + r * 2 * n_grids, t_indices + r * 2 * n_grids,
-            hits + r * n_grids, [&](int i, float a, float b) { t0[i] = a; t1[i] = b; }, t_term[r]);
+        auto emit = [&](int i, float a, float b) { t0[i] = a; t1[i] = b; };
+        const float *ts = t_sorted + r * 2 * n_grids;
+        const int64_t *ti = t_indices + r * 2 * n_grids;
+        const uint8_t *hr = hits + r * n_grids;
+        // the kernels' instantiations: one grid level recomputes the ray/box interval, LOOK = 4 cells
+        if (n_grids == 1)
+            counts[r] = ced::traverse_ray_frame<ced::kFrameLook, true>(G, S, start_coarse != 0, o, d, near_planes[r], far_plane, ts, ti, hr, emit, t_term[r]);
+        else
+            counts[r] = ced::traverse_ray_frame<ced::kFrameLook, false>(G, S, start_coarse != 0, o, d, near_planes[r], far_plane, ts, ti, hr, emit, t_term[r]);
     }
     return CED_OK;
 }

@@ -136,6 +136,16 @@ __global__ __launch_bounds__(THREADS) void field_kernel(FieldArgs A)
     const int wave = tid >> 6;
     const int g = lane >> 4, c = lane & 15;
 
+    int64_t n_eff = A.n;
+    if (A.n_dev) {
+        const int64_t nd = *A.n_dev;
+        n_eff = nd < n_eff ? nd : n_eff;
+    }
+    const int64_t n_tiles = (n_eff + TILE - 1) / TILE;
+    // a workgroup without a tile leaves before staging anything (launches are sized by a host-side upper bound of
+    // the sample count; the exact count comes from device memory)
+    if ((A.spread_tiles ? (int64_t)blockIdx.x * 4 : (int64_t)blockIdx.x * FIELD_WAVES) >= n_tiles) return;
+
     // stage weights + level tables into LDS
     {
         const f4 *src = reinterpret_cast<const f4 *>(A.weights);
@@ -150,13 +160,6 @@ __global__ __launch_bounds__(THREADS) void field_kernel(FieldArgs A)
     }
     __syncthreads();
 
-
-    int64_t n_eff = A.n;
-    if (A.n_dev) {
-        const int64_t nd = *A.n_dev;
-        n_eff = nd < n_eff ? nd : n_eff;
-    }
-    const int64_t n_tiles = (n_eff + TILE - 1) / TILE;
     if (A.stagger > 0) {
         // Waves w, w+4, w+8 of a workgroup share a SIMD and run the same program: offset their phases so
         // that their MFMA-dense and VALU-dense stretches interleave instead of colliding.
@@ -191,15 +194,21 @@ __global__ __launch_bounds__(THREADS) void field_kernel(FieldArgs A)
         int64_t sidx[NT];
         int64_t ridx[NT];
         float px[NT][3], tq[NT];
+        bool any_used = !A.rays_mode;
 #pragma unroll
         for (int j = 0; j < NT; ++j) {
             int64_t s = tile * TILE + 16 * j + c;
             s = s < n_eff ? s : n_eff - 1;
             sidx[j] = s;
             if (A.rays_mode) {
-                const int64_t r = A.ray_idx32 ? (int64_t)A.ray_idx32[s] : A.ray_idx[s];
+                // a negative ray index marks an unused sample slot (the frame renderer's slot-major sample layout):
+                // it is evaluated on ray 0 at t = 0 and its outputs land in its own, never-read slot
+                const int64_t r_in = A.ray_idx32 ? (int64_t)A.ray_idx32[s] : A.ray_idx[s];
+                const bool used = r_in >= 0;
+                const int64_t r = used ? r_in : 0;
+                any_used = any_used || used;
                 ridx[j] = r;
-                const float tm2 = A.t0[s] + A.t1[s];
+                const float tm2 = used ? A.t0[s] + A.t1[s] : 0.0f;
 #pragma unroll
                 for (int a = 0; a < 3; ++a) px[j][a] = A.rays_o[3 * r + a] + (A.rays_d[3 * r + a] * tm2) / 2.0f;
                 tq[j] = A.t_per_ray ? A.timestamps[r] : A.timestamps[0];
@@ -210,6 +219,7 @@ __global__ __launch_bounds__(THREADS) void field_kernel(FieldArgs A)
                 tq[j] = A.t[s];
             }
         }
+        if (__ballot(any_used) == 0ull) continue;            // a tile of unused slots only (wave-uniform)
 
         float B[NT][16];
         f4 D[NT][4];
@@ -551,7 +561,6 @@ __global__ __launch_bounds__(256) void hash_backward_kernel(HashBwdArgs A)
 }
 
 int g_field_stagger = 0;          // field kernel: start-up phase offset between the waves of a SIMD, in s_sleep(127) units
-int g_field_max_blocks = 256;
 int g_field_spread_tiles = 1;     // field kernels: deal tiles across all CUs first (ced_set_option)
 bool g_march_early_out = true;    // frame renderer: conservative brick-level early-out (ced_set_option)
 
@@ -617,6 +626,8 @@ int launch_field(const ced_field_desc *d, FieldArgs &A, void *stream)
     // byte offsets are 32-bit
     CED_REQUIRE(d->hash.total_entries * (uint64_t)((A.table_dtype ? 4 : 8) * (A.temporal ? 4 : 1)) < (1ull << 32),
                 "field_forward: hash table larger than 4 GiB");
+    CED_REQUIRE(d->max_workgroups >= 0 && d->max_workgroups <= 65536, "field_forward: max_workgroups=%d", d->max_workgroups);
+    A.max_blocks = d->max_workgroups;
     A.stagger = g_field_stagger;
     A.spread_tiles = g_field_spread_tiles;
     if (d->mlp_precision != CED_MLP_F32) {
@@ -628,7 +639,8 @@ int launch_field(const ced_field_desc *d, FieldArgs &A, void *stream)
         const int64_t n_tiles = (A.n + 16 * nt - 1) / (16 * nt);
         const int waves = threads / 64;
         int64_t blocks = A.spread_tiles ? (n_tiles + 3) / 4 : (n_tiles + waves - 1) / waves;
-        if (blocks > g_field_max_blocks) blocks = g_field_max_blocks;     // one resident workgroup per CU, persistent over tiles
+        const int cap = A.max_blocks > 0 ? A.max_blocks : kFieldBlocksDefault;
+        if (blocks > cap) blocks = cap;                                   // one resident workgroup per CU, persistent over tiles
         hipLaunchKernelGGL(kernel, dim3((unsigned)blocks), dim3(threads), 0, (hipStream_t)stream, A);
     };
     const int sel = (d->time_mode ? 1 : 0) | (A.table_dtype ? 2 : 0) | (A.temporal ? 4 : 0);
@@ -662,11 +674,6 @@ extern "C" int ced_set_option(const char *key, int value)
     if (strcmp(key, "field_stagger") == 0) {
         CED_REQUIRE(value >= 0 && value <= 64, "set_option: field_stagger must be 0..64");
         ced::g_field_stagger = value;
-        return CED_OK;
-    }
-    if (strcmp(key, "field_max_blocks") == 0) {
-        CED_REQUIRE(value >= 1 && value <= 65536, "set_option: field_max_blocks must be 1..65536");
-        ced::g_field_max_blocks = value;
         return CED_OK;
     }
     if (strcmp(key, "field_spread_tiles") == 0) {

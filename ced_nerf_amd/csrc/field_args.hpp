@@ -24,6 +24,7 @@ struct FieldArgs {
     int stagger;                                      // start-up phase offset between SIMD-mates (s_sleep(127) units)
     int spread_tiles;                                 // tile -> wave mapping (field.hip); ced_set_option("field_spread_tiles")
     int level_mode;                                   // 2 bits per gather slot: 0 mixed, 1 all dense, 2 all hashed
+    int max_blocks;                                   // workgroups of the launch (ced_field_desc.max_workgroups; <= 0: one per CU)
     const void *table;
     float scale[CED_MAX_LEVELS];
     uint32_t res[CED_MAX_LEVELS], offset[CED_MAX_LEVELS], size[CED_MAX_LEVELS], hashed[CED_MAX_LEVELS];
@@ -31,7 +32,7 @@ struct FieldArgs {
 
 extern bool g_march_early_out;
 extern int g_field_spread_tiles;
-extern int g_field_max_blocks;       // workgroups per field launch (<= CUs); fewer leaves CUs to other frames' kernels
+constexpr int kFieldBlocksDefault = 256;      // one persistent workgroup per CU
 
 // Fills the field/hash parts of A from the descriptor, validates, and launches on `stream`.
 int launch_field(const ced_field_desc *d, FieldArgs &A, void *stream);

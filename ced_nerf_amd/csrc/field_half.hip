@@ -61,6 +61,15 @@ __global__ __launch_bounds__(THREADS) void field_half_kernel(FieldArgs A)
     const int wave = tid >> 6;
     const int g = lane >> 4, c = lane & 15;
 
+    int64_t n_eff = A.n;
+    if (A.n_dev) {
+        const int64_t nd = *A.n_dev;
+        n_eff = nd < n_eff ? nd : n_eff;
+    }
+    const int64_t n_tiles = (n_eff + TILE - 1) / TILE;
+    // a workgroup without a tile leaves before staging anything (see field.hip)
+    if ((A.spread_tiles ? (int64_t)blockIdx.x * 4 : (int64_t)blockIdx.x * WAVES) >= n_tiles) return;
+
     {
         const f4 *src = reinterpret_cast<const f4 *>(A.weights);
         f4 *dst = reinterpret_cast<f4 *>(lds);
@@ -74,13 +83,6 @@ __global__ __launch_bounds__(THREADS) void field_half_kernel(FieldArgs A)
     }
     __syncthreads();
 
-
-    int64_t n_eff = A.n;
-    if (A.n_dev) {
-        const int64_t nd = *A.n_dev;
-        n_eff = nd < n_eff ? nd : n_eff;
-    }
-    const int64_t n_tiles = (n_eff + TILE - 1) / TILE;
     const float extent[3] = { A.aabb[3] - A.aabb[0], A.aabb[4] - A.aabb[1], A.aabb[5] - A.aabb[2] };
 
     // tiles are dealt in groups of four (one per SIMD) across all workgroups first: see field.hip
@@ -95,15 +97,20 @@ __global__ __launch_bounds__(THREADS) void field_half_kernel(FieldArgs A)
         int64_t sidx[NT];
         int64_t ridx[NT];
         float px[NT][3], tq[NT];
+        bool any_used = !A.rays_mode;
 #pragma unroll
         for (int j = 0; j < NT; ++j) {
             int64_t s = tile * TILE + 16 * j + c;
             s = s < n_eff ? s : n_eff - 1;
             sidx[j] = s;
             if (A.rays_mode) {
-                const int64_t r = A.ray_idx32 ? (int64_t)A.ray_idx32[s] : A.ray_idx[s];
+                // negative ray index = unused sample slot (see field.hip)
+                const int64_t r_in = A.ray_idx32 ? (int64_t)A.ray_idx32[s] : A.ray_idx[s];
+                const bool used = r_in >= 0;
+                const int64_t r = used ? r_in : 0;
+                any_used = any_used || used;
                 ridx[j] = r;
-                const float tm2 = A.t0[s] + A.t1[s];
+                const float tm2 = used ? A.t0[s] + A.t1[s] : 0.0f;
 #pragma unroll
                 for (int a = 0; a < 3; ++a) px[j][a] = A.rays_o[3 * r + a] + (A.rays_d[3 * r + a] * tm2) / 2.0f;
                 tq[j] = A.t_per_ray ? A.timestamps[r] : A.timestamps[0];
@@ -114,6 +121,8 @@ __global__ __launch_bounds__(THREADS) void field_half_kernel(FieldArgs A)
                 tq[j] = A.t[s];
             }
         }
+
+        if (__ballot(any_used) == 0ull) continue;            // a tile of unused slots only (wave-uniform)
 
         h8 Bh[NT][2], Bl[NT][2];
         f4 D[NT][4];
@@ -320,7 +329,8 @@ int launch_field_half(FieldArgs &A, int time_mode, int precision, void *stream)
         const int64_t n_tiles = (A.n + 16 * nt - 1) / (16 * nt);
         const int waves = threads / 64;
         int64_t blocks = A.spread_tiles ? (n_tiles + 3) / 4 : (n_tiles + waves - 1) / waves;
-        if (blocks > g_field_max_blocks) blocks = g_field_max_blocks;     // one resident workgroup per CU, persistent over tiles
+        const int cap = A.max_blocks > 0 ? A.max_blocks : kFieldBlocksDefault;
+        if (blocks > cap) blocks = cap;                                   // one resident workgroup per CU, persistent over tiles
         hipLaunchKernelGGL(kernel, dim3((unsigned)blocks), dim3(threads), 0, (hipStream_t)stream, A);
     };
     const int sel = (time_mode ? 1 : 0) | (A.table_dtype ? 2 : 0) | (A.temporal ? 4 : 0);

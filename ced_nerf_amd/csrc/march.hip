@@ -89,9 +89,6 @@ __global__ __launch_bounds__(256) void traverse_kernel(TraverseArgs A)
     const int m = A.grid.n_grids;
     const bool fill = A.mode != 0;
     float t_term;
-#ifdef CED_MARCH_PROFILE
-    unsigned long long mp_acc[8], mp_t;
-#endif
     const int n = traverse_ray(
         A.grid, o, d, near, far, A.t_sorted + r * 2 * m, A.t_indices + r * 2 * m, A.hits + r * m,
         [&](int i, float t0, float t1) {
@@ -101,11 +98,7 @@ __global__ __launch_bounds__(256) void traverse_kernel(TraverseArgs A)
                 if (A.ray_indices) A.ray_indices[out_base + i] = r;
             }
         },
-        t_term
-#ifdef CED_MARCH_PROFILE
-        , mp_acc, mp_t
-#endif
-    );
+        t_term);
     A.counts[r] = n;
     if (A.termination_planes) A.termination_planes[r] = t_term;
     if (A.packed_info_out) { A.packed_info_out[2 * r] = out_base; A.packed_info_out[2 * r + 1] = n; }
@@ -145,7 +138,7 @@ extern "C" int ced_traverse_grids(int64_t n_rays, const float *rays_o, const flo
     if (mode == 1 || mode == 3)
         CED_REQUIRE(base && t_starts && t_ends, "traverse_grids: fill mode needs base/t_starts/t_ends");
     if (mode == 2) CED_REQUIRE(limit > 0 && t_starts && t_ends, "traverse_grids: over-allocate needs limit > 0");
-    ced::TraverseArgs A{ n_rays, rays_o, rays_d, ced::GridSpec{ binaries, aabbs, n_grids, res, step_size, cone_angle, limit, nullptr, 0, 0 },
+    ced::TraverseArgs A{ n_rays, rays_o, rays_d, ced::GridSpec{ binaries, aabbs, n_grids, res, step_size, cone_angle, limit },
                          near_planes, far_planes, rays_mask, t_sorted, t_indices, hits, mode, base, counts, t_starts,
                          t_ends, ray_indices, termination_planes, packed_info_out };
     dim3 block(256), grid((unsigned)((n_rays + 255) / 256));

@@ -61,6 +61,7 @@ class ShardedRenderer:
         self.render_fn = render_fn or self._hip_render
         self.shape = None
         self.tracer = None             # optional ops.FrameTracer handed to the native frame call
+        self.field_max_workgroups = 0  # workgroups of this renderer's field launches (0 = one per CU); PipelinedRenderer sets it
         self.field_stream = None       # optional stream shared with other in-flight frames (PipelinedRenderer)
         self.force_collective = force_collective   # run the shard/gather/un-permute path even when world == 1
         # world == 1 without a collective: still walk the rays in 8x8-tile order (a wave's 64 rays are then one
@@ -79,13 +80,14 @@ class ShardedRenderer:
         if self.units == 1:
             return render_image_test(self.max_samples, self.field, self.estimator, Rays(rays_o, rays_d),
                                      timestamps=timestamps, tracer=self.tracer, field_stream=self.field_stream,
-                                     **self.render_kwargs)
+                                     field_max_workgroups=self.field_max_workgroups, **self.render_kwargs)
         u = self.units
         ts = timestamps.reshape(-1).float()
         ts = ts.expand(u).contiguous() if ts.numel() == 1 else ts      # one time for all groups, or one per group
         rgb, op, dp, totals = render_frames_test(
             self.max_samples, self.field, self.estimator, Rays(rays_o.view(u, -1, 3), rays_d.view(u, -1, 3)), timestamps=ts,
-            tracer=self.tracer, field_stream=self.field_stream, **self.render_kwargs)
+            tracer=self.tracer, field_stream=self.field_stream, field_max_workgroups=self.field_max_workgroups,
+            **self.render_kwargs)
         return rgb.view(-1, 3), op.view(-1, 1), dp.view(-1, 1), sum(totals)
 
     def set_rays(self, origins: torch.Tensor, viewdirs: torch.Tensor) -> None:
@@ -208,14 +210,14 @@ class PipelinedRenderer:
                  field_max_blocks: Optional[int] = 128):
         from concurrent.futures import ThreadPoolExecutor
         self.lanes = list(lanes)
-        # With several frames in flight a field launch is capped at half the CUs (process-wide library option): two
-        # frames' field kernels then run side by side and the third frame's marching / compositing launches find
-        # free CUs instead of queueing behind a chip-wide kernel (+5 % frames/s with 3 lanes; a frame alone is
-        # faster with all 256, which `restore_field_blocks()` puts back).
+        # With several frames in flight a field launch is capped at half the CUs (a per-call property of the lanes'
+        # native calls, ced_field_desc.max_workgroups): two frames' field kernels then run side by side and the third
+        # frame's marching / compositing launches find free CUs instead of queueing behind a chip-wide kernel (+5 %
+        # frames/s with 3 lanes).  A renderer outside this pipeline keeps one workgroup per CU: nothing is process-wide.
         self.field_max_blocks = field_max_blocks if len(self.lanes) > 1 else None
-        if self.field_max_blocks is not None and torch.cuda.is_available() and str(self.lanes[0].device) != "cpu":
-            from . import _lib
-            _lib.check(_lib.lib().ced_set_option(b"field_max_blocks", int(self.field_max_blocks)))
+        if self.field_max_blocks is not None:
+            for lane in self.lanes:
+                lane.field_max_workgroups = int(self.field_max_blocks)
         self.async_gather = bool(async_gather)
         self.comm_stream = None
         self.streams = [torch.cuda.Stream(device=l.device) if torch.cuda.is_available() and str(l.device) != "cpu"
@@ -332,11 +334,6 @@ class PipelinedRenderer:
         for t in threads:
             t.result()
         return outs
-
-    @staticmethod
-    def restore_field_blocks() -> None:
-        from . import _lib
-        _lib.check(_lib.lib().ced_set_option(b"field_max_blocks", 256))
 
     def wait_gathers(self) -> None:
         """Make the caller's stream wait for every gather issued so far (async_gather mode)."""

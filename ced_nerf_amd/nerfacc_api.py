@@ -216,6 +216,17 @@ class OccGridEstimator(torch.nn.Module):
         self.register_buffer("grid_coords", grid_coords.reshape(self.cells_per_lvl, self.DIM), persistent=False)
         self.register_buffer("grid_indices", torch.arange(self.cells_per_lvl), persistent=False)
 
+    def occupancy_accel(self) -> torch.Tensor:
+        """The brick distance field of `binaries` for the frame renderer (ops.build_occupancy_accel), rebuilt when the
+        grid has changed (set_binaries, _update) and kept otherwise: a video renders hundreds of frames per grid."""
+        b = self.binaries
+        key = (b.data_ptr(), b._version, str(b.device))
+        if getattr(self, "_accel_key", None) != key:
+            with torch.cuda.device(b.device):
+                self._accel = ops.build_occupancy_accel(b.contiguous())
+            self._accel_key = key
+        return self._accel
+
     def set_binaries(self, binaries: torch.Tensor, occs: Optional[torch.Tensor] = None) -> None:
         """Load a precomputed grid (e.g. from a checkpoint's 'occupancy_grid' state)."""
         assert binaries.shape == self.binaries.shape, (binaries.shape, self.binaries.shape)

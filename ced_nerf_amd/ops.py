@@ -366,6 +366,31 @@ def finalize_pixels_(bkgd, rgb, opacity, depth):
 # ----------------------------------------------------------------------------------------------
 # frame renderer (the whole render_image_test loop in one native call)
 # ----------------------------------------------------------------------------------------------
+def build_occupancy_accel(binaries: torch.Tensor) -> torch.Tensor:
+    """ced_build_occupancy_accel: the brick distance field of an occupancy grid [m,res,res,res] (bool / uint8), as a
+    uint8 tensor to hand to the frame renderer.  Rebuild it when the grid changes (train_real.py:332-336)."""
+    assert binaries.is_cuda and binaries.is_contiguous() and binaries.ndim == 4
+    _check_current_device(binaries.device.index, "binaries")
+    m, res = binaries.shape[0], binaries.shape[1]
+    L = _lib.lib()
+    need = int(L.ced_occupancy_accel_bytes(m, res))
+    if need < 0:
+        raise ValueError("build_occupancy_accel: unsupported grid size")
+    accel = torch.empty((need,), device=binaries.device, dtype=torch.uint8)
+    _lib.check(L.ced_build_occupancy_accel(_p(_as_u8(binaries)), m, res, _p(accel), need, _stream()), "build_occupancy_accel")
+    return accel
+
+
+def _with_workgroups(desc: _lib.FieldDesc, max_workgroups: int) -> _lib.FieldDesc:
+    """The descriptor with its per-call launch property `max_workgroups` set (a copy when it differs)."""
+    if int(max_workgroups) == int(desc.max_workgroups):
+        return desc
+    d2 = _lib.FieldDesc()
+    C.memmove(C.byref(d2), C.byref(desc), C.sizeof(_lib.FieldDesc))
+    d2.max_workgroups = int(max_workgroups)
+    return d2
+
+
 class FrameTracer:
     """Event pairs + per-iteration counters for ced_render_image_test (see ced_frame_trace)."""
 
@@ -412,9 +437,12 @@ _frame_ws_lock = __import__("threading").Lock()
 
 def render_image_test_native(desc: _lib.FieldDesc, rays_o, rays_d, binaries, aabbs, near_plane, far_plane,
                              render_step_size, cone_angle, early_stop_eps, max_samples, timestamps, t_per_ray, bkgd,
-                             tracer: Optional[FrameTracer] = None, field_stream: Optional[torch.cuda.Stream] = None):
+                             tracer: Optional[FrameTracer] = None, field_stream: Optional[torch.cuda.Stream] = None,
+                             accel: Optional[torch.Tensor] = None, max_workgroups: int = 0):
     """ced_render_image_test.  Returns (rgb [n,3], opacity [n,1], depth [n,1], total_samples).
-    field_stream: optional stream shared by concurrently rendered frames for their field kernels."""
+    field_stream: optional stream shared by concurrently rendered frames for their field kernels; accel: the grid's
+    brick distance field (build_occupancy_accel; None = built inside the call); max_workgroups: workgroups of a field
+    launch (0 = one per CU)."""
     _chk(rays_o, torch.float32, "rays_o"); _chk(rays_d, torch.float32, "rays_d")
     _chk(aabbs, torch.float32, "aabbs"); _chk(timestamps, torch.float32, "timestamps")
     _chk(bkgd, torch.float32, "render_bkgd", allow_none=True)
@@ -437,14 +465,14 @@ def render_image_test_native(desc: _lib.FieldDesc, rays_o, rays_d, binaries, aab
         ws = _frame_ws.get(key)
         if ws is None or ws[0].numel() < need:
             ws = (torch.empty((max(need, 1),), device=dev, dtype=torch.uint8),
-                  ws[1] if ws is not None else torch.zeros((32,), dtype=torch.int64).pin_memory())
+                  ws[1] if ws is not None else torch.zeros((512,), dtype=torch.int64).pin_memory())
             _frame_ws[key] = ws
     rgb = torch.empty((n, 3), device=dev, dtype=torch.float32)
     opacity = torch.empty((n, 1), device=dev, dtype=torch.float32)
     depth = torch.empty((n, 1), device=dev, dtype=torch.float32)
     total = C.c_int64(0)
-    rc = L.ced_render_image_test(C.byref(desc), n, _p(rays_o), _p(rays_d), _p(_as_u8(binaries)), m, res, _p(aabbs),
-                                 float(near_plane), float(far_plane), float(render_step_size), float(cone_angle),
+    rc = L.ced_render_image_test(C.byref(_with_workgroups(desc, max_workgroups)), n, _p(rays_o), _p(rays_d),
+                                 _p(_as_u8(binaries)), m, res, _p(aabbs), _p(accel), float(near_plane), float(far_plane), float(render_step_size), float(cone_angle),
                                  float(early_stop_eps), int(max_samples), _p(timestamps), int(bool(t_per_ray)), _p(bkgd),
                                  _p(rgb), _p(opacity), _p(depth), _p(ws[0]), ws[0].numel(), C.c_void_p(ws[1].data_ptr()),
                                  C.byref(total), C.byref(tracer.struct) if tracer is not None else None,
@@ -455,7 +483,8 @@ def render_image_test_native(desc: _lib.FieldDesc, rays_o, rays_d, binaries, aab
 
 def render_frames_test_native(desc: _lib.FieldDesc, n_frames: int, rays_o, rays_d, binaries, aabbs, near_plane, far_plane,
                               render_step_size, cone_angle, early_stop_eps, max_samples, frame_times, bkgd,
-                              tracer: Optional[FrameTracer] = None, field_stream: Optional[torch.cuda.Stream] = None):
+                              tracer: Optional[FrameTracer] = None, field_stream: Optional[torch.cuda.Stream] = None,
+                              accel: Optional[torch.Tensor] = None, max_workgroups: int = 0):
     """ced_render_frames_test: `n_frames` frames (rays frame-major, [n_frames * rays_per_frame, 3]) through shared
     launches, every frame on its own schedule.  Returns (rgb [N,3], opacity [N,1], depth [N,1], [total_samples per frame])."""
     _chk(rays_o, torch.float32, "rays_o"); _chk(rays_d, torch.float32, "rays_d")
@@ -478,14 +507,14 @@ def render_frames_test_native(desc: _lib.FieldDesc, n_frames: int, rays_o, rays_
         ws = _frame_ws.get(key)
         if ws is None or ws[0].numel() < need:
             ws = (torch.empty((max(need, 1),), device=dev, dtype=torch.uint8),
-                  ws[1] if ws is not None else torch.zeros((32,), dtype=torch.int64).pin_memory())
+                  ws[1] if ws is not None else torch.zeros((512,), dtype=torch.int64).pin_memory())
             _frame_ws[key] = ws
     rgb = torch.empty((n, 3), device=dev, dtype=torch.float32)
     opacity = torch.empty((n, 1), device=dev, dtype=torch.float32)
     depth = torch.empty((n, 1), device=dev, dtype=torch.float32)
     totals = (C.c_int64 * n_frames)()
-    rc = L.ced_render_frames_test(C.byref(desc), n_frames, n // n_frames, _p(rays_o), _p(rays_d), _p(_as_u8(binaries)), m,
-                                  res, _p(aabbs), float(near_plane), float(far_plane), float(render_step_size),
+    rc = L.ced_render_frames_test(C.byref(_with_workgroups(desc, max_workgroups)), n_frames, n // n_frames, _p(rays_o),
+                                  _p(rays_d), _p(_as_u8(binaries)), m, res, _p(aabbs), _p(accel), float(near_plane), float(far_plane), float(render_step_size),
                                   float(cone_angle), float(early_stop_eps), int(max_samples), _p(frame_times), _p(bkgd),
                                   _p(rgb), _p(opacity), _p(depth), _p(ws[0]), ws[0].numel(), C.c_void_p(ws[1].data_ptr()),
                                   totals, C.byref(tracer.struct) if tracer is not None else None,

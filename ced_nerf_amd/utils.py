@@ -154,12 +154,13 @@ def render_image_test(
     timestamps: Optional[torch.Tensor] = None,
     tracer=None,
     field_stream=None,
+    field_max_workgroups: int = 0,
 ):
     """Iterative eval renderer with per-iteration early termination (cednerf/utils.py:153-318).
     Returns (rgb, opacity, depth, total_samples).  `alpha_thre` is accepted and unused, as in the
-    reference.  The whole loop runs inside the native library (ced_render_image_test): three
-    launches per iteration; `render_image_test_staged` is the same algorithm driven from Python
-    through the nerfacc-shaped ops."""
+    reference.  The whole loop runs inside the native library (ced_render_image_test): four
+    launches per iteration, the N_samples schedule computed on the device; `render_image_test_staged` is the
+    same algorithm driven from Python through the nerfacc-shaped ops."""
     if timestamps is None:
         raise NotImplementedError("DNGPradianceField needs timestamps (dnerf path of cednerf/utils.py:186-194)")
     rays, rays_shape, N_rays = _flatten_rays(rays)
@@ -170,7 +171,7 @@ def render_image_test(
     rgb, opacity, depth, total = ops.render_image_test_native(
         radiance_field._descriptor(), rays_o, rays_d, estimator.binaries, estimator.aabbs.contiguous(), near_plane,
         far_plane, render_step_size, cone_angle, early_stop_eps, max_samples, ts, bool(radiance_field.training), bk,
-        tracer=tracer, field_stream=field_stream)
+        tracer=tracer, field_stream=field_stream, accel=estimator.occupancy_accel(), max_workgroups=field_max_workgroups)
     return (rgb.view((*rays_shape[:-1], -1)), opacity.view((*rays_shape[:-1], -1)),
             depth.view((*rays_shape[:-1], -1)), total)
 
@@ -191,6 +192,7 @@ def render_frames_test(
     timestamps: Optional[torch.Tensor] = None,
     tracer=None,
     field_stream=None,
+    field_max_workgroups: int = 0,
 ):
     """`render_image_test` for a stack of frames in one native call (ced_render_frames_test): rays.origins / viewdirs
     are [F, ..., 3] (F <= 8 frames of equal size), timestamps holds F times.  The frames share the launches of an
@@ -212,7 +214,7 @@ def render_frames_test(
     rgb, opacity, depth, totals = ops.render_frames_test_native(
         radiance_field._descriptor(), n_frames, rays_o, rays_d, estimator.binaries, estimator.aabbs.contiguous(),
         near_plane, far_plane, render_step_size, cone_angle, early_stop_eps, max_samples, ts, bk,
-        tracer=tracer, field_stream=field_stream)
+        tracer=tracer, field_stream=field_stream, accel=estimator.occupancy_accel(), max_workgroups=field_max_workgroups)
     return rgb.view((*shape[:-1], 3)), opacity.view((*shape[:-1], 1)), depth.view((*shape[:-1], 1)), totals
 
 

@@ -60,10 +60,7 @@ def render_video(radiance_field, estimator, rays_of_frame: Callable[[int], Rays]
     def times(lane, step):
         return torch.cat([timestamps_of_frame(i).reshape(-1)[:1] for i in frames_of(lane, step)])
 
-    try:
-        steps = pipe.render_steps(times, n_steps, before_frame)
-    finally:
-        pipe.restore_field_blocks()
+    steps = pipe.render_steps(times, n_steps, before_frame)
     frames = []
     for step, row in enumerate(steps):
         for lane, out in enumerate(row):

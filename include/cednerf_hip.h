@@ -64,6 +64,9 @@ typedef struct ced_field_desc {
     int32_t use_div_offsets;     /* model.py:356-358 */
     int32_t time_mode;           /* 0 none, 1 SinusoidalEncoder, 2 SinusoidalEncoderWithExp (model.py:386-396) */
     int32_t mlp_precision;       /* CED_MLP_*: arithmetic of the three MLPs (below) */
+    int32_t max_workgroups;      /* workgroups of a field launch: 0 = one per CU (256); callers that keep several
+                                    frames in flight pass 128 so that two frames' field kernels run side by side.
+                                    A per-call launch property (copy the descriptor to vary it), not process state. */
     const void *packed_weights;  /* device: blob written by ced_pack_field_weights[_half] for that precision */
     uint64_t packed_floats;      /* its size in 32-bit words: ced_packed_weight_words() */
     ced_hash_desc hash;
@@ -72,16 +75,15 @@ typedef struct ced_field_desc {
 int ced_version(void);
 const char *ced_last_error_string(void);
 
-/* Tuning knobs (process-wide).  "field_variant": launch geometry of the fused field kernel,
+/* Diagnostic knobs (process-wide; results are identical for every setting -- launch properties that callers vary
+ * per call, such as the workgroup count of a field launch, are descriptor fields instead).  "field_variant": launch geometry of the fused field kernel,
  * 0 = 4 column tiles x 512 threads, 1 = 2 x 512, 2 = 2 x 768 (default), 3 = 2 x 1024, 4 = 1 x 1024;
  * "half_variant": the same for the half-precision kernels, 0 = 2 x 768 (default), 1 = 2 x 512, 2 = 2 x 1024;
  * "field_spread_tiles": 1 (default) deals the sample tiles of a launch across all CUs in groups of four before
  * any CU takes more (shorter last round, lower frame latency), 0 = contiguous tiles per workgroup;
- * "field_max_blocks": workgroups per field launch, 1..256 (default 256 = one per CU; frames in flight use 128 so
- * that two frames' field kernels run side by side);
  * "field_stagger": start-up phase offset between the waves of a SIMD (0 = none, default);
- * "march_early_out": 1 (default) lets ced_render_image_test stop walking a ray once a dilated
- * brick mask proves nothing occupied lies ahead, 0 walks every cell.  Results are identical for every setting. */
+ * "march_early_out": 1 (default) lets the frame renderer's marching cross empty space through the brick distance
+ * field, 0 walks every cell. */
 int ced_set_option(const char *key, int value);
 
 /* Arithmetic of xyz_wrap / mlp_base / mlp_head (everything else is fp32 in every mode):
@@ -148,28 +150,33 @@ int ced_traverse_grids(int64_t n_rays, const float *rays_o, const float *rays_d,
                        float *termination_planes, int64_t *packed_info_out, void *stream);
 
 /* ---- occupancy acceleration structure of the frame renderer ----
- * A per-brick (8^3 cells) Chebyshev distance field over `binaries`: the frame renderer's marching sphere-traces it
- * through empty space and re-enters the exact cell walk in closed form (csrc/march_accel.hpp), so the emitted samples
- * are those of nerfacc.traverse_grids (cednerf/utils.py:241-264) bit for bit.  Build it once per occupancy-grid update
- * (train_real.py:332-336) and hand it to ced_render_image_test / ced_render_frames_test; NULL there = built per call.
+ * Chebyshev distance fields over `binaries` (per 8^3-cell brick and per cell): the frame renderer's marching
+ * sphere-traces them through empty space and re-enters the exact cell walk in closed form (csrc/march_accel.hpp), so
+ * the emitted samples are those of nerfacc.traverse_grids (cednerf/utils.py:241-264) bit for bit.  Build it once per
+ * occupancy-grid update (train_real.py:332-336) and hand it to ced_render_image_test / ced_render_frames_test; with
+ * NULL there only the brick-level field is built, inside every call.
  * accel: device memory of ced_occupancy_accel_bytes(n_grids, res) bytes. */
 int64_t ced_occupancy_accel_bytes(int32_t n_grids, int32_t res);
 int ced_build_occupancy_accel(const uint8_t *binaries, int32_t n_grids, int32_t res, void *accel, int64_t accel_bytes,
                               void *stream);
 
-/* HOST functions (validation aids, no GPU needed): the distance field built on the host (dist_host: n_grids * nb^3
- * bytes, nb = ceil(res / 8)); the closed-form DDA re-entry  k = 0; while (k < kcap && *x < tau) { *prev = *x; *x += d; ++k; }
+/* HOST functions (validation aids, no GPU needed): the acceleration structure built on the host (accel_host:
+ * ced_occupancy_accel_bytes() bytes of host memory, same layout as the device one); the closed-form DDA re-entry  k = 0; while (k < kcap && *x < tau) { *prev = *x; *x += d; ++k; }
  * and the frame renderer's marching of n_rays rays with the SAME code the device runs (march_accel.hpp is host +
  * device): counts[r] samples (<= limit) at t_starts/t_ends[r * limit + i]; t_term[r] is the termination plane when
- * counts[r] == limit (unspecified otherwise: such a ray is dead, cednerf/utils.py:303-306).  dist may be NULL
- * (plain cell-by-cell walk).  All pointers are host pointers. */
-int ced_host_build_occupancy_accel(const uint8_t *binaries_host, int32_t n_grids, int32_t res, uint8_t *dist_host);
+ * counts[r] == limit (unspecified otherwise: such a ray is dead, cednerf/utils.py:303-306).  accel_mode: 0 = plain
+ * cell-by-cell walk, 1 = brick field only (what a render call builds for itself), 2 = brick + cell fields (what
+ * ced_build_occupancy_accel provides).  use_lattice: far skips start from the table of first lattice points per
+ * binade, as in a frame with cone_angle == 0 (every near plane must then be a point of the lattice t_0 = near_planes[0],
+ * t_{k+1} = t_k + step: the frame's near plane or an earlier termination plane).  All pointers are host pointers. */
+int ced_host_build_occupancy_accel(const uint8_t *binaries_host, int32_t n_grids, int32_t res, uint8_t *accel_host);
 int32_t ced_host_count_steps(float *x, float d, float tau, int32_t kcap, float *prev);
 int ced_host_march_frame(int64_t n_rays, const float *rays_o, const float *rays_d, const uint8_t *binaries,
                          int32_t n_grids, int32_t res, const float *aabbs, const float *near_planes, float far_plane,
                          float step_size, float cone_angle, int32_t limit, const float *t_sorted,
-                         const int64_t *t_indices, const uint8_t *hits, const uint8_t *dist, int32_t start_coarse,
-                         int32_t *counts, float *t_starts, float *t_ends, float *t_term);
+                         const int64_t *t_indices, const uint8_t *hits, const uint8_t *accel_host, int32_t accel_mode,
+                         int32_t use_lattice, int32_t start_coarse, int32_t *counts, float *t_starts, float *t_ends,
+                         float *t_term);
 
 /* HOST function (validation aid): the kernels' empty-space skip -- advance t_last by whole steps
  * dt = clamp(t*cone_angle, step_size, 1e10) until t_last + dt/2 >= target -- evaluated on the host
@@ -322,7 +329,8 @@ int ced_generate_rays_hypercam(int32_t width, int32_t height, const float *orien
 /* Optional per-iteration trace of ced_render_image_test (host struct, host arrays of `capacity`
  * entries, each may be NULL).  field_begin/field_end are caller-created hipEvent_t handles that the
  * renderer records on `stream` around the field-kernel launch of iteration i, so a benchmark can
- * time that kernel live without perturbing the launch sequence. */
+ * time that kernel live without perturbing the launch sequence.  Events of iterations >= n_iters may have been
+ * recorded around empty launches (the host enqueues ahead of the device-side schedule). */
 typedef struct ced_frame_trace {
     int32_t capacity;        /* in  */
     int32_t n_iters;         /* out: iterations executed */
@@ -341,22 +349,25 @@ int64_t ced_render_image_test_workspace_bytes(int64_t n_rays, int32_t n_grids, i
  * render_step_size, render_bkgd, cone_angle, alpha_thre, early_stop_eps, timestamps)
  * -- cednerf/utils.py:153-318, the eval / GUI frame renderer (callers train_real.py:481-493,
  * :541-553, gui.py:215-228), as ONE call: ray/AABB setup, then per iteration one marching launch,
- * one fused field launch and one compositing launch, and the background / depth normalisation
- * at the end.  Same schedule and per-ray sample sets as the reference loop.  `alpha_thre` is not
- * a parameter because the reference ignores it in this function.
+ * one fused field launch, one compositing launch and a one-wave scheduling launch that computes the next
+ * iteration's N_samples = clamp(N_rays // N_alive, min, 64) ON THE DEVICE, and the background / depth
+ * normalisation at the end.  Same schedule and per-ray sample sets as the reference loop; unlike it
+ * (utils.py:231: one device->host sync per iteration) the host never waits for an iteration: it enqueues up to
+ * CED_FRAME_RUN_AHEAD (default 2) iterations beyond the last one whose plan it has seen published in `host_stats`.
+ * `alpha_thre` is not a parameter because the reference ignores it in this function.
  *   rays_o, rays_d [n_rays,3]; binaries [n_grids,res,res,res] bytes; aabbs [n_grids,6];
+ *   accel: device, from ced_build_occupancy_accel for these binaries, or NULL (built inside the call);
  *   timestamps: device [1] (t_per_ray = 0, eval) or [n_rays] (t_per_ray = 1); bkgd: device [3] or NULL;
  *   outputs rgb [n_rays,3], opacity [n_rays], depth [n_rays] (overwritten);
  *   workspace: device scratch of ced_render_image_test_workspace_bytes() bytes;
- *   host_stats: PINNED host memory, >= 32 bytes (per-iteration counters land here);
+ *   host_stats: PINNED host memory, >= 2048 bytes, private to this call while it runs (the scheduling launches
+ *   publish {rays alive, done, sequence number} there; the call's table of lattice points travels through it);
  *   total_samples_out: host, receives the number of field evaluations (utils.py:307,317).
- *   field_stream: NULL, or a second stream on which the field kernel is launched (event-ordered with
- *   `stream`): callers with several frames in flight share one field stream between them so the
- *   MFMA-bound field launches serialise while everything else of one frame overlaps another's.
- * Unlike the other entry points this one BLOCKS: like the reference loop (utils.py:231) it reads
- * the alive-ray count back once per iteration. */
+ *   field_stream: NULL, or a second stream on which the field kernel is launched (event-ordered with `stream`).
+ * The call returns when the frame is complete (it ends with one stream synchronise to read the sample count and
+ * the per-iteration record back). */
 int ced_render_image_test(const ced_field_desc *field, int64_t n_rays, const float *rays_o, const float *rays_d,
-                          const uint8_t *binaries, int32_t n_grids, int32_t res, const float *aabbs,
+                          const uint8_t *binaries, int32_t n_grids, int32_t res, const float *aabbs, const void *accel,
                           float near_plane, float far_plane, float render_step_size, float cone_angle,
                           float early_stop_eps, int32_t max_samples,
                           const float *timestamps, int32_t t_per_ray, const float *bkgd,
@@ -369,17 +380,16 @@ int ced_render_image_test(const ced_field_desc *field, int64_t n_rays, const flo
  * launches of an iteration -- one marching, one field and one compositing launch cover the alive rays of all the
  * frames -- while EVERY FRAME KEEPS ITS OWN reference loop: N_samples = clamp(N_rays // N_alive, min, 64) on its own
  * counts, its own `iteration < max_samples` end.  Each frame's pixels and sample count are therefore exactly those of
- * ced_render_image_test on that frame alone; what changes is that the field launches are n_frames times larger
- * (a launch's start-up and tail cost as much as ~40 us of its ~250 us at 800x800).
+ * ced_render_image_test on that frame alone; what changes is that the launches are n_frames times larger.
  *   rays_o, rays_d [n_frames * rays_per_frame, 3] (frame-major); frame_times: device [n_frames], one time per frame;
  *   outputs rgb [n_frames * rays_per_frame, 3], opacity, depth; workspace of
- *   ced_render_frames_test_workspace_bytes() bytes; host_stats: PINNED host memory, >= 256 bytes;
- *   total_samples_out: host [n_frames].  Everything else as ced_render_image_test. */
+ *   ced_render_frames_test_workspace_bytes() bytes; total_samples_out: host [n_frames].
+ *   Everything else as ced_render_image_test. */
 int64_t ced_render_frames_test_workspace_bytes(int32_t n_frames, int64_t rays_per_frame, int32_t n_grids, int32_t res,
                                                float cone_angle, int32_t max_samples);
 int ced_render_frames_test(const ced_field_desc *field, int32_t n_frames, int64_t rays_per_frame,
                            const float *rays_o, const float *rays_d, const uint8_t *binaries, int32_t n_grids,
-                           int32_t res, const float *aabbs, float near_plane, float far_plane,
+                           int32_t res, const float *aabbs, const void *accel, float near_plane, float far_plane,
                            float render_step_size, float cone_angle, float early_stop_eps, int32_t max_samples,
                            const float *frame_times, const float *bkgd, float *rgb, float *opacity, float *depth,
                            void *workspace, int64_t workspace_bytes, int64_t *host_stats,

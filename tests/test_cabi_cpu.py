@@ -21,8 +21,11 @@ def test_library_exports_every_declared_symbol():
 def test_struct_layout_matches_header():
     from ced_nerf_amd import _lib
     assert C.sizeof(_lib.HashDesc) == 16 + 5 * 64 + 8 + 8
-    assert C.sizeof(_lib.FieldDesc) == 24 + 4 + 3 * 4 + 8 + 8 + C.sizeof(_lib.HashDesc)
-    assert _lib.FieldDesc.hash.offset == 56
+    # aabb[6], moving_step, 4 int32 (use_div_offsets, time_mode, mlp_precision, max_workgroups), 4 bytes of padding,
+    # packed_weights, packed_floats, hash
+    assert C.sizeof(_lib.FieldDesc) == 24 + 4 + 4 * 4 + 4 + 8 + 8 + C.sizeof(_lib.HashDesc)
+    assert _lib.FieldDesc.max_workgroups.offset == 40 and _lib.FieldDesc.packed_weights.offset == 48
+    assert _lib.FieldDesc.hash.offset == 64
 
 
 def test_argument_errors_are_reported_not_thrown():
@@ -46,11 +49,17 @@ def test_argument_errors_are_reported_not_thrown():
     assert L.ced_render_image_test_workspace_bytes(640000, 1, 128, 0.0, 1024) > 0
     assert L.ced_render_image_test_workspace_bytes(10, 9, 128, 0.0, 16) < 0                                  # too many grids
     tot = C.c_int64(-1)
-    assert L.ced_render_image_test(C.byref(d), 0, None, None, None, 1, 128, None, 0.0, 1e10, 5e-3, 0.0, 1e-4, 64, None, 0,
+    assert L.ced_render_image_test(C.byref(d), 0, None, None, None, 1, 128, None, None, 0.0, 1e10, 5e-3, 0.0, 1e-4, 64, None, 0,
                                    None, None, None, None, None, 0, None, C.byref(tot), None, None, None) == 0   # no rays
     assert tot.value == 0
-    assert L.ced_render_image_test(C.byref(d), 5, None, None, None, 1, 128, None, 0.0, 1e10, 5e-3, 0.0, 1e-4, 64, None, 0,
+    assert L.ced_render_image_test(C.byref(d), 5, None, None, None, 1, 128, None, None, 0.0, 1e10, 5e-3, 0.0, 1e-4, 64, None, 0,
                                    None, None, None, None, None, 0, None, C.byref(tot), None, None, None) == -1
+    # brick field + scratch (padded to 256 bytes), cell field + scratch
+    assert L.ced_occupancy_accel_bytes(1, 128) == 2 * 16 ** 3 + 2 * 128 ** 3
+    assert L.ced_occupancy_accel_bytes(4, 100) == (2 * 4 * 13 ** 3 + 255) // 256 * 256 + 2 * 4 * 100 ** 3
+    assert L.ced_occupancy_accel_bytes(1, 4096) < 0
+    assert L.ced_build_occupancy_accel(None, 1, 128, None, 0, None) == -1
+    assert L.ced_set_option(b"field_max_blocks", 128) == -1          # a per-call descriptor field now, not process state
 
 
 def test_closed_form_skip_matches_sequential_recurrence(oracle):

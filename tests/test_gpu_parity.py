@@ -953,7 +953,6 @@ def test_sharded_renderer_units_equal_frames_alone(oracle):
         for l, o in enumerate(row):
             for k in range(3):
                 assert torch.equal(o["rgb"][k], alone[3 * l + k][0]) and torch.equal(o["opacity"][k], alone[3 * l + k][1])
-    pipe.restore_field_blocks()
     with pytest.raises(ValueError):
         bad = ShardedRenderer(f, est, 1, 0, torch.device(DEV), render_kwargs=rk, units=2)
         bad.set_rays(torch.stack(os_), torch.stack(ds_))                       # 3 frames do not split into 2 groups

@@ -66,7 +66,19 @@ def test_count_steps_equals_the_float_recurrence(hip):
         _check_count(hip, x, d, tau, kcap)
 
 
-def _march_case(hip, oracle, sc, limit, near, start_coarse, use_dist=True):
+def _build_accel(hip, binaries):
+    m, res = binaries.shape[0], binaries.shape[1]
+    nbytes = int(hip.ced_occupancy_accel_bytes(m, res))
+    accel = np.zeros((nbytes,), np.uint8)
+    assert hip.ced_host_build_occupancy_accel(P(binaries), m, res, P(accel)) == 0
+    nb = (res + 7) // 8
+    bdist = accel[:m * nb ** 3].reshape(m, nb, nb, nb)
+    off = (2 * m * nb ** 3 + 255) // 256 * 256
+    cdist = accel[off:off + m * res ** 3].reshape(m, res, res, res)
+    return accel, bdist, cdist
+
+
+def _march_case(hip, oracle, sc, limit, near, start_coarse, accel_mode=2, use_lattice=False, want_out=False):
     cfg, rk = sc["cfg"], sc["render"]
     o = np.ascontiguousarray(sc["origins"].reshape(-1, 3)); d = np.ascontiguousarray(sc["viewdirs"].reshape(-1, 3))
     n = o.shape[0]
@@ -79,15 +91,13 @@ def _march_case(hip, oracle, sc, limit, near, start_coarse, use_dist=True):
     w = oracle.traverse_grids(o, d, binaries.astype(bool), aabbs, near, far, rk["render_step_size"], rk["cone_angle"], limit,
                               True, np.ones(n, bool), ts, ti, hits)
     wc = w["packed_info"][:, 1]
-    nb = (res + 7) // 8
-    dist = np.empty((m, nb, nb, nb), np.uint8)
-    assert hip.ced_host_build_occupancy_accel(P(binaries), m, res, P(dist)) == 0
+    accel, dist, cdist = _build_accel(hip, binaries)
     counts = np.empty(n, np.int32); t0 = np.zeros((n, limit), np.float32); t1 = np.zeros((n, limit), np.float32)
     tt = np.zeros(n, np.float32)
     hits8 = np.ascontiguousarray(hits.astype(np.uint8)); ts = np.ascontiguousarray(ts, np.float32); ti = np.ascontiguousarray(ti, np.int64)
     rc = hip.ced_host_march_frame(n, P(o), P(d), P(binaries), m, res, P(aabbs), P(near), float(rk["far_plane"]),
                                   float(rk["render_step_size"]), float(rk["cone_angle"]), limit, P(ts), P(ti), P(hits8),
-                                  P(dist) if use_dist else None, int(start_coarse), P(counts), P(t0), P(t1), P(tt))
+                                  P(accel), int(accel_mode), int(use_lattice), int(start_coarse), P(counts), P(t0), P(t1), P(tt))
     assert rc == 0
     assert_bitexact(counts.astype(np.int64), wc.astype(np.int64), "sample counts")
     mask = np.arange(limit)[None, :] < counts[:, None]
@@ -95,7 +105,36 @@ def _march_case(hip, oracle, sc, limit, near, start_coarse, use_dist=True):
     assert_bitexact(t1[mask], w["t_ends"], "t_ends")
     full = wc == limit
     assert_bitexact(tt[full], w["termination_planes"][full], "termination planes of the rays that stay alive")
+    if want_out:
+        return wc, w["termination_planes"]
     return int(wc.sum()), int(full.sum()), dist
+
+
+@pytest.mark.parametrize("name,wh", [("dnerf", (56, 40)), ("hypernerf", (32, 44))])
+def test_march_frame_chained_iterations_like_the_frame_loop(hip, oracle, name, wh):
+    """The frame loop's use: iteration 0 from the frame's near plane with the sphere trace on, then every iteration
+    resumes the rays that used their whole budget at their termination planes (cednerf/utils.py:301-306) with a larger
+    budget.  With cone_angle == 0 all of it happens on one lattice, and far skips go through the lattice table."""
+    from ced_nerf_amd import synthetic as S
+    sc = S.make_scene(name, wh[0], wh[1], "trained", log2_hashmap_size=10)
+    if name == "dnerf":
+        sc["render"]["near_plane"] = 0.0
+    n = wh[0] * wh[1]
+    o_all, d_all = sc["origins"].reshape(-1, 3).copy(), sc["viewdirs"].reshape(-1, 3).copy()
+    alive = np.arange(n)
+    near = np.full((n,), sc["render"]["near_plane"], np.float32)
+    total = 0
+    for it, limit in enumerate((1 if sc["render"]["cone_angle"] == 0 else 4, 4, 6, 13, 64, 64)):
+        if alive.size == 0:
+            break
+        sub = dict(sc); sub["origins"] = o_all[alive][None]; sub["viewdirs"] = d_all[alive][None]
+        counts, term = _march_case(hip, oracle, sub, limit, near[alive].copy(), it == 0, accel_mode=2, use_lattice=True,
+                                   want_out=True)
+        total += int(counts.sum())
+        keep = counts == limit
+        near[alive[keep]] = term[keep]
+        alive = alive[keep]
+    assert total > 3000
 
 
 @pytest.mark.parametrize("name,wh", [("dnerf", (64, 48)), ("hypernerf", (40, 56)), ("dynerf", (56, 40))])
@@ -111,11 +150,12 @@ def test_march_frame_matches_oracle_on_the_dataset_shaped_scenes(hip, oracle, na
             if resume:       # later iterations: every ray resumes at its own termination plane
                 near = (near + rng.uniform(0, 6, size=n)).astype(np.float32)
             for start_coarse in (True, False):
-                s, full, dist = _march_case(hip, oracle, sc, limit, near, start_coarse)
-                total += s
-    assert total > 20000 and dist.max() >= 4 and dist.min() == 0
-    # without the distance field the same code is the plain cell-by-cell walk
-    _march_case(hip, oracle, sc, 5, np.full((n,), sc["render"]["near_plane"], np.float32), True, use_dist=False)
+                for mode in (2, 1):          # brick + cell fields (a caller's accel); brick field only (built per call)
+                    s, full, dist = _march_case(hip, oracle, sc, limit, near, start_coarse, accel_mode=mode)
+                    total += s
+    assert total > 40000 and dist.max() >= 4 and dist.min() == 0
+    # without the distance fields the same code is the plain cell-by-cell walk
+    _march_case(hip, oracle, sc, 5, np.full((n,), sc["render"]["near_plane"], np.float32), True, accel_mode=0)
 
 
 def _fuzz_scene(seed):
@@ -162,16 +202,15 @@ def test_march_frame_matches_oracle_on_random_configurations(hip, oracle, seed):
         near = np.full((n,), sc["render"]["near_plane"], np.float32)
         if rng.random() < 0.5:
             near = (near + rng.uniform(0, 3, size=n)).astype(np.float32)
-        _march_case(hip, oracle, sc, limit, near, bool(rng.integers(2)))
+        _march_case(hip, oracle, sc, limit, near, bool(rng.integers(2)), accel_mode=int(rng.integers(1, 3)))
 
 
-def test_distance_field_is_the_chebyshev_brick_distance(hip):
+def test_distance_fields_are_chebyshev_distances(hip):
     rng = np.random.default_rng(2)
     res = 40                                              # 5 bricks per axis
     b = np.zeros((2, res, res, res), np.uint8)
     b[0, 3, 17, 39] = 1; b[0, 30, 2, 9] = 1               # bricks (0,2,4) and (3,0,1); level 1 stays empty
-    dist = np.empty((2, 5, 5, 5), np.uint8)
-    assert hip.ced_host_build_occupancy_accel(P(b), 2, res, P(dist)) == 0
+    _, dist, cdist = _build_accel(hip, b)
     occ = [(0, 2, 4), (3, 0, 1)]
     for x in range(5):
         for y in range(5):
@@ -179,3 +218,20 @@ def test_distance_field_is_the_chebyshev_brick_distance(hip):
                 want = min(max(abs(x - a), abs(y - c), abs(z - e)) for a, c, e in occ)
                 assert dist[0, x, y, z] == want
     assert (dist[1] == 16).all()                          # nothing within reach: the cap + 1 lower bound
+    # cell level: exact up to 15, a lower bound (>= 16, from the brick field) beyond
+    X, Y, Z = np.meshgrid(np.arange(res), np.arange(res), np.arange(res), indexing="ij")
+    true = np.minimum(np.maximum.reduce([abs(X - 3), abs(Y - 17), abs(Z - 39)]),
+                      np.maximum.reduce([abs(X - 30), abs(Y - 2), abs(Z - 9)]))
+    near = true <= 15
+    assert np.array_equal(cdist[0][near], true[near].astype(np.uint8))
+    assert (cdist[0][~near] >= 16).all() and (cdist[0][~near] <= true[~near]).all()
+    assert (cdist[1] >= 16).all()
+    # random occupancy on a grid that is not a multiple of the brick size, against brute force
+    res = 21
+    b = (rng.uniform(size=(1, res, res, res)) < 0.002).astype(np.uint8)
+    _, dist, cdist = _build_accel(hip, b)
+    pts = np.argwhere(b[0])
+    X, Y, Z = np.meshgrid(np.arange(res), np.arange(res), np.arange(res), indexing="ij")
+    true = np.min([np.maximum.reduce([abs(X - p[0]), abs(Y - p[1]), abs(Z - p[2])]) for p in pts], axis=0)
+    near = true <= 15
+    assert np.array_equal(cdist[0][near], true[near].astype(np.uint8)) and (cdist[0][~near] <= true[~near]).all()

@@ -25,7 +25,6 @@ for prec in ("f32", "f16x2", "f16"):
             one.set_rays(T(o)[None], T(d)[None]); singles.append(one)
         r = ShardedRenderer(f, est, 1, 0, torch.device(dev), max_samples=1024, render_kwargs=rk, tile_order=True, units=units)
         r.set_rays(torch.stack(os_), torch.stack(ds_)); lanes.append(r)
-    PipelinedRenderer.restore_field_blocks()
     alone = [l.render(ts) for l in singles]              # one frame at a time, full-chip launches
     ref = [dict(rgb=torch.cat([alone[k * units + u]["rgb"] for u in range(units)]),
                 depth=torch.cat([alone[k * units + u]["depth"] for u in range(units)]),
