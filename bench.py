@@ -58,6 +58,13 @@ def parse():
                          "iteration, each on its own schedule; 1 = ced_render_image_test per frame")
     ap.add_argument("--frames-in-flight", type=int, default=3,
                     help="independent frames rendered concurrently per GPU (own stream + host thread each)")
+    ap.add_argument("--scaling", default="weak", choices=["weak", "strong"],
+                    help="weak: a step renders frames_in_flight x frames_per_call frames PER GPU (per-GPU work fixed); "
+                         "strong: that many frames in total, every frame's rays dealt tile-cyclically over the GPUs and "
+                         "every frame's shard on its own render_image_test schedule (total work fixed)")
+    ap.add_argument("--min-seconds", type=float, default=2.0,
+                    help="after the contractual K-step window, further K-step windows are timed until this much time has "
+                         "been measured in all (at least 5, at most 24 windows): median / p10 / p90 in `windows`")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-single-frame", action="store_true",
                     help="skip the one-frame-alone latency measurement after the timed region (profiling runs: every "
@@ -169,15 +176,18 @@ def main():
     # one frame per GPU, its rays dealt tile-cyclically over the ranks; the lanes run concurrently.
     lanes = max(1, args.frames_in_flight)
     per_call = max(1, min(8, args.frames_per_call))
+    # weak scaling: a unit of a call is this rank's share of `world` consecutive frames (per-GPU work fixed);
+    # strong scaling: a unit is this rank's share of ONE frame (total work fixed)
+    wf = world if args.scaling == "weak" else 1
     if per_call > 1:
         # several frames per call need every rank's share of every frame group to be the same number of rays
         # (true for 800x800 on 1/2/4/8 GPUs); otherwise fall back to one frame per call
-        ids = cdist.tile_cyclic_assignment(per_call * world, args.height, args.width, world)[1]
-        group = world * args.height * args.width
+        ids = cdist.tile_cyclic_assignment(per_call * wf, args.height, args.width, world)[1]
+        group = wf * args.height * args.width
         if len({len(s) for s in ids}) != 1 or any(len(set(np.bincount(s // group, minlength=per_call).tolist())) != 1 for s in ids):
             per_call = 1
     tdt = np.float16 if args.table_dtype == "f16" else np.float32
-    n_frames = lanes * per_call * world
+    n_frames = lanes * per_call * wf
     sc = S.make_scene(args.scene, args.width, args.height, args.regime, azim_deg=30.0, table_dtype=tdt)
     cfg = sc["cfg"]
 
@@ -198,7 +208,7 @@ def main():
     from ced_nerf_amd import ops
     lane_renderers, tracers = [], []
     for l in range(lanes):
-        fr = frames[l * per_call * world:(l + 1) * per_call * world]
+        fr = frames[l * per_call * wf:(l + 1) * per_call * wf]
         r = cdist.ShardedRenderer(field, est, world, rank, dev, max_samples=args.max_samples, render_kwargs=rk,
                                   tile_order=os.environ.get("CED_TILE_ORDER", "1") != "0", units=per_call)
         r.set_rays(torch.stack([T(f["origins"]) for f in fr]), torch.stack([T(f["viewdirs"]) for f in fr]))
@@ -249,6 +259,36 @@ def main():
     if world > 1:
         dist.barrier()
     dt = time.perf_counter() - t0
+
+    def reduce_window(dt_w, samples_w):
+        tt_w = torch.tensor([dt_w, float(samples_w)], device=dev, dtype=torch.float64)
+        if world > 1:
+            tmax_w = tt_w.clone(); dist.all_reduce(tmax_w, op=dist.ReduceOp.MAX)
+            tsum_w = tt_w.clone(); dist.all_reduce(tsum_w, op=dist.ReduceOp.SUM)
+            return float(tmax_w[0]), float(tsum_w[1])
+        return dt_w, float(samples_w)
+
+    # further windows of the same K steps (untraced), each bracketed like the first: run-to-run spread of the number
+    window_rates = []
+    dt_first, samples_first = reduce_window(dt, samples_local)
+    window_rates.append(samples_first / dt_first)
+    timed = dt_first
+    n_extra = 0
+    while (timed < args.min_seconds or n_extra < 4) and n_extra < 23:
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+        t_w = time.perf_counter()
+        rows_w = renderer.render_steps(ts, args.steps, before_frame=lambda l, s_: setattr(lane_renderers[l], "tracer", None))
+        s_w = sum(o["local_samples"] for row in rows_w for o in row)
+        del rows_w
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        d_w, s_tot = reduce_window(time.perf_counter() - t_w, s_w)
+        window_rates.append(s_tot / d_w)
+        timed += d_w
+        n_extra += 1
     intervals = []
     for l in range(lanes):                      # the last min(steps, 24) steps' field launches
         for tr in tracers[l][:min(args.steps, len(tracers[l]))]:
@@ -307,14 +347,14 @@ def main():
         if world > 1:
             dist.destroy_process_group()
         return
-    n_rays_step = n_frames * args.width * args.height
+    n_rays_step = n_frames * args.width * args.height          # frames of a step x rays per frame, over all ranks
     # latency of ONE frame rendered alone (no other frame in flight), for reference (field launches on all CUs again)
     for r_ in lane_renderers:
         r_.field_max_workgroups = 0          # one frame alone: field launches on all CUs
     torch.cuda.synchronize()
     t1 = time.perf_counter()
     single_field = {"ms": 0.0, "launches": 0, "units": 0.0}
-    single_ms = None
+    single_ms, single_stats = None, None
     if not args.no_single_frame:
         alone = lane_renderers[0]
         if per_call > 1:                                # one frame (per GPU) per call, as ced_render_image_test renders it
@@ -324,24 +364,37 @@ def main():
         alone.tracer = tracers[0][0]
         alone.render_local(ts)                          # first call on this stream allocates its workspace
         torch.cuda.synchronize()
-        t1 = time.perf_counter()
-        for _ in range(5):
+        for _ in range(5):                              # with HIP events around the field launches (roofline_single_frame)
             alone.render_local(ts)                      # this rank's shard only: the other ranks have left by now
             ms = tracers[0][0].field_ms()
             single_field["ms"] += sum(ms); single_field["launches"] += len(ms)
             single_field["units"] += float(sum(it["n_new"] for it in tracers[0][0].iterations()))
-        torch.cuda.synchronize()
-        single_ms = (time.perf_counter() - t1) / 5 * 1e3
+        alone.tracer = None
+        single_times = []
+        for _ in range(20):                             # the latency itself: untraced, every frame timed on its own
+            torch.cuda.synchronize()
+            t1 = time.perf_counter()
+            alone.render_local(ts)
+            torch.cuda.synchronize()
+            single_times.append((time.perf_counter() - t1) * 1e3)
+        single_ms = float(np.median(single_times))
+        single_stats = {"median": single_ms, "p10": float(np.quantile(single_times, 0.1)),
+                        "p90": float(np.quantile(single_times, 0.9)), "frames": len(single_times)}
     fp16 = sc["params"]["hash"]["table"].dtype == np.float16
     line = {
         "metric": "samples_per_sec (render_image_test, 800x800 D-NeRF lego-shaped synthetic)",
         "value": samples_total / dt, "unit": "samples/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-        "ms_per_step": 1e3 * dt / args.steps, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "ms_per_step": 1e3 * dt / args.steps, "higher_is_better": True, "scaling": args.scaling, "vs_baseline": None,
         "dtype": {"f32": "f32", "f16x2": "f32 (MLP GEMMs: split-fp16 MFMA, 22-bit operands, fp32 accumulate)",
                   "f16": "f16 MLP operands, fp32 accumulate; rest f32"}[args.mlp_precision],
         "mlp_precision": args.mlp_precision, "data": "synthetic",
         "rays_per_sec": n_rays_step * args.steps / dt,
-        "ms_per_frame": 1e3 * dt / args.steps / (lanes * per_call), "single_frame_latency_ms": single_ms,
+        "ms_per_frame": 1e3 * dt / args.steps / (lanes * per_call),
+        "single_frame_latency_ms": single_ms, "single_frame_latency_stats_ms": single_stats,
+        "windows": {"n": len(window_rates), "steps_each": args.steps, "seconds": timed, "unit": "samples/s",
+                    "median": float(np.median(window_rates)), "p10": float(np.quantile(window_rates, 0.1)),
+                    "p90": float(np.quantile(window_rates, 0.9)), "first": window_rates[0],
+                    "note": "value = the first (contractual) window; the others repeat it untraced"},
         "samples_per_ray": samples_total / (n_rays_step * args.steps),
         "config": {"workload": f"{args.scene} {args.width}x{args.height} render_image_test max_samples={args.max_samples}, "
                                f"hash L=16 F=2 T=2^21 {'fp16' if fp16 else 'fp32'} table, 64-wide MLPs, "
@@ -350,7 +403,8 @@ def main():
                    "rays_per_step": n_rays_step,
                    "parallelism": f"{lanes} call(s) in flight per GPU x {per_call} frame(s) per call, every frame on its own "
                                   f"render_image_test schedule; each frame's rays tile-cyclic over {world} GPU(s) + "
-                                  f"all-gather of pixels"},
+                                  f"all-gather of pixels ({args.scaling} scaling: "
+                                  f"{'a unit = one rank share of ' + str(world) + ' consecutive frames' if args.scaling == 'weak' else 'a unit = one rank share of one frame'})"},
     }
     fk = prof.get("field", None)
     if fk and fk["launches"] > 0:
@@ -363,15 +417,21 @@ def main():
         samples_per_launch = fk["units"] / fk["launches"]
         tflops = samples_per_launch * ALG_FLOPS_PER_SAMPLE / (avg_ms * 1e-3) / 1e12
         gbs = samples_per_launch * (ALG_BYTES_PER_SAMPLE_F16 if fp16 else ALG_BYTES_PER_SAMPLE_F32) / (avg_ms * 1e-3) / 1e9
-        traffic = None
+        traffic, traffic_source = None, None
         exact_kernel = args.mlp_precision == "f32"
-        pmc_json = args.pmc_json or os.path.join(ROOT, "profiles", f"r01_final_{args.mlp_precision}_pmc.json")
+        pmc_json = args.pmc_json
+        if pmc_json is None:       # the newest committed PMC passes of this workload (profiles/rNN_final_<mode>_pmc.json)
+            import glob
+            cands = sorted(glob.glob(os.path.join(ROOT, "profiles", f"r[0-9][0-9]_final_{args.mlp_precision}_pmc.json")))
+            pmc_json = cands[-1] if cands else ""
         if args.scene == "dnerf" and not fp16 and os.path.exists(pmc_json):
             try:        # HBM bytes per launch from the committed PMC passes of this same workload
                 pj = json.load(open(pmc_json))
                 kpat = "void ced::field_kernel" if exact_kernel else "void ced::field_half_kernel"
                 k = [v for n, v in pj.items() if n.startswith(kpat)][0]
                 traffic = k["fetch_bytes_per_launch"] + k["write_bytes_per_launch"]
+                traffic_source = {"file": os.path.relpath(pmc_json, ROOT), "commit": pj.get("_source_commit"),
+                                  "note": pj.get("_note")}
             except Exception:
                 traffic = None
         # Which roofline bounds the field kernel depends on the MLP arithmetic.  f32: the exact fp32 MFMA chain is
@@ -382,7 +442,8 @@ def main():
         mfma_peak = PEAK_F32_MFMA_TFLOPS if exact else PEAK_F16_MFMA_TFLOPS
         alg_bytes = ALG_BYTES_PER_SAMPLE_F16 if fp16 else ALG_BYTES_PER_SAMPLE_F32
         kname = "field_kernel" if exact else "field_half_kernel"
-        common = {"avg_launch_ms": avg_ms, "launches": fk["launches"], "samples_per_launch": samples_per_launch,
+        common = {"traffic_source": traffic_source,
+                  "avg_launch_ms": avg_ms, "launches": fk["launches"], "samples_per_launch": samples_per_launch,
                   "avg_launch_ms_raw": raw_avg_ms,
                   "field_busy_over_wall": busy_ms / max(span_ms, 1e-9),
                   "note": "%d call(s) in flight x %d frame(s) per call: avg_launch_ms = (time with a field kernel executing) "
@@ -416,6 +477,38 @@ def main():
         for k_, v_ in others.items():
             v_["parity"] = notes[k_]
         line["other_mlp_precisions"] = others
+    if world > 1 and last_row is not None:
+        # the exchange, checked: lane 0's gathered frames of the last timed step (every rank's shard, all-gathered and
+        # un-permuted) against the same frames rendered whole by this rank alone.  A shard runs its own image-global
+        # schedule, so sample counts differ (reported) and pixels agree to the north-star 1e-4, not bit for bit.
+        from ced_nerf_amd.utils import render_image_test
+        renderer.wait_gathers()
+        torch.cuda.synchronize()
+        o0 = last_row[0]
+        worst = {"rgb": 0.0, "opacity": 0.0, "depth": 0.0}
+        single_total, n_over, n_pix = 0, 0, 0
+        n_check = min(o0["rgb"].shape[0], 3)
+        for k in range(n_check):
+            fk_ = frames[k]
+            single = render_image_test(args.max_samples, field, est, Rays(T(fk_["origins"]), T(fk_["viewdirs"])),
+                                       timestamps=ts, **rk)
+            single_total += int(single[3])
+            over = None
+            for nm, a, b in (("rgb", o0["rgb"][k], single[0]), ("opacity", o0["opacity"][k], single[1]),
+                             ("depth", o0["depth"][k], single[2])):
+                dlt = (a - b.reshape(a.shape)).abs().amax(dim=-1)
+                worst[nm] = max(worst[nm], float(dlt.max()))
+                if nm != "opacity":
+                    over = (dlt > 1e-4) if over is None else (over | (dlt > 1e-4))
+            n_over += int(over.sum()); n_pix += int(over.numel())
+        # A shard's schedule restarts every ray's march at other termination planes than the whole frame's does; the
+        # reference's DDA set-up is redone at every restart (nerfacc), so a sample whose mid-point lies within rounding
+        # of a cell boundary can be in one sample set and not in the other: rare pixels (about one in 4e5) differ by
+        # one low-weight sample, i.e. by more than the early-stop bound of 1e-4.
+        line["gather_check"] = {"frames": n_check, "rgb_max_abs": worst["rgb"], "opacity_max_abs": worst["opacity"],
+                                "depth_max_abs": worst["depth"], "samples_single_rank": single_total,
+                                "pixels": n_pix, "pixels_over_1e-4": n_over,
+                                "ok": bool(n_over <= max(2, n_pix // 50000) and max(worst["rgb"], worst["depth"]) <= 5e-3)}
     if not args.no_cpu_baseline:
         line["cpu_baseline"], oracle_out = cpu_baseline(sc, args)
         if world == 1 and args.cpu_stride == 1:

@@ -79,11 +79,13 @@ PROTOTYPES = {
                                          _vp, _vp, _vp]),
     "ced_render_weights": (C.c_int, [_i64, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "ced_accumulate_along_rays": (C.c_int, [_i64, _vp, _vp, _vp, _i32, _vp, _vp]),
+    "ced_reduce_along_rays": (C.c_int, [_i64, _vp, _vp, _i32, _vp, _i32, _i64, _i32, _vp, _vp, _vp]),
     "ced_visibility_mask": (C.c_int, [_i64, _vp, _vp, _vp, _vp, _f, _f, _vp, _vp]),
     "ced_composite_prefix": (C.c_int, [_i64, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "ced_composite_backward": (C.c_int, [_i64, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "ced_frame_to_rgb8": (C.c_int, [_i32, _i32, _vp, _i32, _vp, _vp]),
     "ced_depth_to_u8": (C.c_int, [_i32, _i32, _vp, _i32, _vp, _vp, _vp]),
+    "ced_scatter_pixels": (C.c_int, [_i64, _vp, _i32, _vp, _i32, _vp, _i32, _vp, _i64, _vp, _vp, _vp, _vp, _i32, _i32, _vp]),
     "ced_weight_grad_workspace_bytes": (_i64, [_i64, _i32, _i32]),
     "ced_weight_grad": (C.c_int, [_i64, _vp, _i32, _vp, _i32, _vp, _vp, _i64, _vp]),
     "ced_composite_step": (C.c_int, [_i64, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _f, _i32, _vp, _vp, _vp]),

@@ -252,6 +252,58 @@ __global__ __launch_bounds__(256) void composite_backward_kernel(int64_t n_rays,
     }
 }
 
+// reduce_along_rays (cednerf/render.py:8-39): out[ray, c] (+)= weights[i, c or 0] * values[i, c] for every sample i of
+// the ray -- torch's scatter_reduce_ into a zero tensor.  Like that op on the GPU, arbitrary (unsorted) ray indices
+// are accumulated with float atomics; consecutive samples of one ray -- the ray-packed case of every caller -- are
+// summed across the wave first, so a run costs one atomic.  counts[ray] += 1 per sample serves reduce="mean".
+__global__ __launch_bounds__(256) void reduce_along_rays_kernel(int64_t n, int n_ch, const int64_t *__restrict__ ray_indices,
+                                                                const float *__restrict__ values,
+                                                                const float *__restrict__ weights, int w_ch, int64_t n_rays,
+                                                                float *__restrict__ out, int32_t *__restrict__ counts)
+{
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int lane = threadIdx.x & 63;
+    const bool in = i < n;
+    const int64_t r = in ? ray_indices[i] : -1;
+    const bool ok = in && r >= 0 && r < n_rays;
+    // runs of equal ray index inside the wave: the last lane of a run adds the run's sum
+    const int64_t r_prev = __shfl_up(r, 1, 64), r_next = __shfl_down(r, 1, 64);
+    const bool head = lane == 0 || r_prev != r;
+    const bool tail = lane == 63 || r_next != r;
+    for (int c = 0; c < n_ch; ++c) {
+        float v = ok ? values[i * n_ch + c] : 0.0f;
+        if (ok && weights) v = weights[i * w_ch + (w_ch > 1 ? c : 0)] * v;
+        int h = head ? 1 : 0;
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) {
+            const float v_up = __shfl_up(v, d, 64);
+            const int h_up = __shfl_up(h, d, 64);
+            if (lane >= d && !h) { v += v_up; h |= h_up; }
+        }
+        if (ok && tail) unsafeAtomicAdd(out + r * n_ch + c, v);
+    }
+    if (counts) {
+        int k = 1, h = head ? 1 : 0;
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) {
+            const int k_up = __shfl_up(k, d, 64);
+            const int h_up = __shfl_up(h, d, 64);
+            if (lane >= d && !h) { k += k_up; h |= h_up; }
+        }
+        if (ok && tail) atomicAdd(counts + r, k);
+    }
+}
+
+// reduce="mean" of scatter_reduce_ with include_self=True (the default the reference relies on): the zero the output
+// started from counts as one element
+__global__ __launch_bounds__(256) void reduce_mean_finish_kernel(int64_t n_rays, int n_ch, const int32_t *__restrict__ counts,
+                                                                 float *__restrict__ out)
+{
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n_rays * n_ch) return;
+    out[i] = out[i] / (float)(counts[i / n_ch] + 1);
+}
+
 }  // namespace ced
 
 extern "C" int ced_composite_backward(int64_t n_rays, const int64_t *packed_info, const float *t_starts, const float *t_ends,
@@ -358,4 +410,29 @@ extern "C" int ced_finalize_pixels(int64_t n_rays, const float *bkgd, float *rgb
     hipLaunchKernelGGL(ced::finalize_kernel, ced::grid_for(n_rays), dim3(256), 0, (hipStream_t)stream, n_rays, bkgd, rgb,
                        opacity, depth);
     return ced::check_launch("finalize_pixels");
+}
+
+extern "C" int ced_reduce_along_rays(int64_t n_samples, const int64_t *ray_indices, const float *values, int32_t n_channels,
+                                     const float *weights, int32_t weight_channels, int64_t n_rays, int32_t mean,
+                                     float *out, int32_t *counts_workspace, void *stream)
+{
+    CED_REQUIRE(n_samples >= 0 && n_rays >= 0 && n_channels >= 1, "reduce_along_rays: bad sizes");
+    CED_REQUIRE(!weights || weight_channels == 1 || weight_channels == n_channels,
+                "reduce_along_rays: weights must have 1 or n_channels columns");
+    CED_REQUIRE(out != nullptr || n_rays == 0, "reduce_along_rays: null output");
+    CED_REQUIRE(!mean || counts_workspace, "reduce_along_rays: reduce=\"mean\" needs a counts workspace of n_rays int32");
+    if (n_rays == 0) return CED_OK;
+    if (hipMemsetAsync(out, 0, (size_t)n_rays * n_channels * 4, (hipStream_t)stream) != hipSuccess ||
+        (mean && hipMemsetAsync(counts_workspace, 0, (size_t)n_rays * 4, (hipStream_t)stream) != hipSuccess))
+        return ced::check_launch("reduce_along_rays (memset)");
+    if (n_samples > 0) {
+        CED_REQUIRE(ray_indices && values, "reduce_along_rays: null pointer");
+        hipLaunchKernelGGL(ced::reduce_along_rays_kernel, ced::grid_for(n_samples), dim3(256), 0, (hipStream_t)stream, n_samples,
+                           (int)n_channels, ray_indices, values, weights, (int)weight_channels, n_rays, out,
+                           mean ? counts_workspace : (int32_t *)nullptr);
+    }
+    if (mean)
+        hipLaunchKernelGGL(ced::reduce_mean_finish_kernel, ced::grid_for(n_rays * n_channels), dim3(256), 0, (hipStream_t)stream,
+                           n_rays, (int)n_channels, counts_workspace, out);
+    return ced::check_launch("reduce_along_rays");
 }

@@ -3,12 +3,11 @@
 // Same algorithm and the same per-ray sample sets as the reference's host loop (image-global schedule
 // N_samples = clamp(N_rays // N_alive, min, 64), termination checked between iterations), but
 //   * an iteration is four launches instead of ~15 kernels + torch glue:
-//       march     : one lane per ALIVE ray (march_accel.hpp: brick distance field through empty space, exact DDA
-//                   where it matters); samples go straight to the ray's own slot range -- the reference's
-//                   over_allocate=True layout (utils.py:258): slot s of a frame owns samples [s*N_samples, +N_samples),
-//                   so there is no count pass, no scan, no atomic and no staging;
-//       field     : the fused field kernel (field.hip / field_half.hip) over the slot ranges (unused slots are marked
-//                   and skipped a tile at a time);
+//       march     : one lane per ALIVE ray (march_accel.hpp: distance fields through empty space, exact DDA where it
+//                   matters); a ray remembers its samples as runs in registers, the workgroup reserves one contiguous
+//                   range of the iteration's sample array with a single atomic and the samples are regenerated
+//                   there: ray-packed and dense, no count pass, no scan, no staging;
+//       field     : the fused field kernel (field.hip / field_half.hip) on those samples (count read from device memory);
 //       composite : per-ray front-to-back compositing over the alive list; survivors are appended to the next
 //                   iteration's list, one range reservation per workgroup;
 //       schedule  : one thread turns the survivor counts into the NEXT iteration's plan on the device -- rays alive,
@@ -53,11 +52,12 @@ struct IterPlan {
     int32_t last[kMaxFrames];        // the frame's loop ends after this iteration (max_samples reached, utils.py:229)
     int32_t used[kMaxFrames];        // the frame's iter_samples, this iteration included (utils.py:236)
     int32_t slot_base[kMaxFrames];   // first ray slot of the frame in this iteration's launches (multiple of kSlotAlign)
-    int32_t samp_base[kMaxFrames];   // first sample slot of the frame: ray slot s owns [samp_base + s*limit, +limit)
+    int32_t samp_bound[kMaxFrames];  // count * limit: the frame's samples of the iteration are at most this many
     int32_t total_slots;             // end of the last frame's ray-slot range
     int32_t done;                    // nothing left: this and every later iteration is an empty launch
     int64_t pad_;
-    int64_t total_samples;           // sample slots of the iteration = sum count*limit (the field kernel's n)
+    int64_t total_samples;           // samples RESERVED in the iteration so far: the marching workgroups add their totals
+                                     // (ray-packed allocation); the field kernel's n once the marching launch is over
     // filled in DURING the iteration by the compositing kernel: low word = survivors appended to the frame's next
     // alive list, high word = samples the frame marched in this iteration
     unsigned long long next[kMaxFrames];
@@ -174,14 +174,15 @@ __device__ __forceinline__ void make_next_plan(const ScheduleArgs &S)
             count = alive;
         }
         N.count[f] = count; N.limit[f] = limit; N.last[f] = last; N.used[f] = used;
-        N.slot_base[f] = slots; N.samp_base[f] = (int)samples;
+        N.slot_base[f] = slots; N.samp_bound[f] = count * limit;
         N.next[f] = 0;
         slots = (slots + count + kSlotAlign - 1) & ~(kSlotAlign - 1);
         samples += (long long)count * limit;
         alive_total += count;
     }
     N.total_slots = slots;
-    N.total_samples = samples;
+    (void)samples;
+    N.total_samples = 0;
     N.done = alive_total == 0 ? 1 : 0;
     S.host[0] = alive_total;                // rays alive entering iteration it + 1: an upper bound for every later one
     S.host[1] = N.done;
@@ -211,47 +212,115 @@ struct MarchArgs {
     const float *t_sorted;
     const int64_t *t_indices;
     const uint8_t *hits;
-    float *t_starts, *t_ends;      // sample slots
-    int32_t *ray_idx;              // ray of every sample slot, -1 for the unused slots of a ray's range
-    int32_t *counts;               // [n_rays] samples the ray marched in this iteration
+    float *t_starts, *t_ends;      // ray-packed samples of the iteration
+    int32_t *ray_idx;              // ray of every sample
+    int32_t *packed;               // [n_rays, 2] (first sample, count) of the ray in this iteration
 };
 
+constexpr int kMaxRuns = 4;        // runs of consecutive samples a ray's walk is remembered by (more: the ray walks twice)
+
+// One lane per alive ray.  The walk does not store its samples: within a run of consecutive samples t_start[j+1] ==
+// t_end[j] and t_end[j] = t_start[j] + dt(t_start[j]), so a ray remembers (first t, length) of up to kMaxRuns runs in
+// registers.  Then the workgroup reserves ONE contiguous range of the iteration's sample array (wave prefix sums +
+// a single returning atomic: the samples stay ray-packed and dense, with no count pass and no staging) and every
+// lane regenerates its samples from its runs -- the same recurrence, the same floats.  A ray with more runs than fit
+// (alternating single occupied cells), or a walk without a step size, simply walks again, storing directly.
 template <bool SINGLE>
-__global__ __launch_bounds__(kMarchThreads, SINGLE ? 4 : 3) void march_frame_kernel(MarchArgs A, const IterPlan *__restrict__ plan,
+__global__ __launch_bounds__(kMarchThreads, SINGLE ? 4 : 3) void march_frame_kernel(MarchArgs A, IterPlan *__restrict__ plan,
                                                                     int first_iteration)
 {
+    constexpr int kWaves = kMarchThreads / 64;
+    __shared__ int wave_tot[kWaves];
+    __shared__ long long block_base;
     const IterPlan &P = *plan;
     const int64_t total = P.total_slots;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     for (int64_t s0 = (int64_t)blockIdx.x * kMarchThreads; s0 < total; s0 += (int64_t)gridDim.x * kMarchThreads) {
         const int f = frame_of_slot(P, A.n_frames, s0);
         if (f < 0) continue;                                 // padding between two frames' slot ranges (whole workgroup)
         const int limit = P.limit[f];
         const int64_t idx = s0 + threadIdx.x - P.slot_base[f];
-        if (idx >= P.count[f]) continue;
+        const bool active = idx < P.count[f];
         const int64_t first = (int64_t)f * A.rays_per_frame;
-        const int64_t r = A.alive ? (int64_t)A.alive[first + idx] : first + idx;
-        const int64_t sbase = (int64_t)P.samp_base[f] + idx * limit;
+        const int64_t r = active ? (A.alive ? (int64_t)A.alive[first + idx] : first + idx) : 0;
         GridSpec grid = A.grid;
         grid.limit = limit;
-        const float o[3] = { A.rays_o[3 * r], A.rays_o[3 * r + 1], A.rays_o[3 * r + 2] };
-        const float d[3] = { A.rays_d[3 * r], A.rays_d[3 * r + 1], A.rays_d[3 * r + 2] };
         const int m = grid.n_grids;
-        float t_term;
-        float *const p0 = A.t_starts + sbase, *const p1 = A.t_ends + sbase;
-        int32_t *const pr = A.ray_idx + sbase;
-        const int n = traverse_ray_frame<kFrameLook, SINGLE>(
-            grid, A.accel, first_iteration != 0, o, d, A.near_planes[r], A.far_plane,
-            SINGLE ? nullptr : A.t_sorted + r * 2 * m, SINGLE ? nullptr : A.t_indices + r * 2 * m,
-            SINGLE ? nullptr : A.hits + r * m,
-            [&](int i, float t0, float t1) {
-                p0[i] = t0;
-                p1[i] = t1;
-                pr[i] = (int32_t)r;
-            },
-            t_term);
-        for (int i = n; i < limit; ++i) pr[i] = -1;
-        A.counts[r] = n;
-        A.near_planes[r] = t_term;
+        float o[3] = { 0.0f, 0.0f, 0.0f }, d[3] = { 0.0f, 0.0f, 1.0f };
+        float near = 0.0f, t_term = 0.0f;
+        float run_t[kMaxRuns];
+        int run_n[kMaxRuns];
+#pragma unroll
+        for (int k = 0; k < kMaxRuns; ++k) { run_t[k] = 0.0f; run_n[k] = 0; }
+        int n = 0, n_runs = 0;
+        if (active) {
+#pragma unroll
+            for (int a = 0; a < 3; ++a) { o[a] = A.rays_o[3 * r + a]; d[a] = A.rays_d[3 * r + a]; }
+            near = A.near_planes[r];
+            float prev_end = 0.0f;
+            n = traverse_ray_frame<kFrameLook, SINGLE>(
+                grid, A.accel, first_iteration != 0, o, d, near, A.far_plane,
+                SINGLE ? nullptr : A.t_sorted + r * 2 * m, SINGLE ? nullptr : A.t_indices + r * 2 * m,
+                SINGLE ? nullptr : A.hits + r * m,
+                [&](int i, float t0, float t1) {
+                    const bool fresh = i == 0 || t0 != prev_end;
+                    if (fresh) ++n_runs;
+                    prev_end = t1;
+                    // run slots as a chain of selects (run_t / run_n stay in registers)
+#pragma unroll
+                    for (int k = 0; k < kMaxRuns; ++k) {
+                        const bool here = n_runs == k + 1;
+                        run_t[k] = (here && fresh) ? t0 : run_t[k];
+                        run_n[k] += here ? 1 : 0;
+                    }
+                },
+                t_term);
+            A.near_planes[r] = t_term;
+        }
+        // wave-inclusive prefix sum of the counts, one reservation per workgroup
+        int incl = n;
+#pragma unroll
+        for (int off = 1; off < 64; off <<= 1) {
+            const int v = __shfl_up(incl, off, 64);
+            if (lane >= off) incl += v;
+        }
+        if (lane == 63) wave_tot[wave] = incl;
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            int run = 0;
+            for (int w = 0; w < kWaves; ++w) { const int t = wave_tot[w]; wave_tot[w] = run; run += t; }
+            block_base = run > 0 ? (long long)atomicAdd(reinterpret_cast<unsigned long long *>(&plan->total_samples),
+                                                        (unsigned long long)run) : 0;
+        }
+        __syncthreads();
+        const int64_t start = (int64_t)block_base + wave_tot[wave] + (incl - n);
+        if (active) {
+            A.packed[2 * r] = (int32_t)start;
+            A.packed[2 * r + 1] = n;
+            float *const p0 = A.t_starts + start, *const p1 = A.t_ends + start;
+            int32_t *const pr = A.ray_idx + start;
+            if (n > 0 && (n_runs > kMaxRuns || !(grid.step_size > 0.0f))) {
+                float unused;                               // the walk again, storing at the final position
+                (void)traverse_ray_frame<kFrameLook, SINGLE>(
+                    grid, A.accel, first_iteration != 0, o, d, near, A.far_plane,
+                    SINGLE ? nullptr : A.t_sorted + r * 2 * m, SINGLE ? nullptr : A.t_indices + r * 2 * m,
+                    SINGLE ? nullptr : A.hits + r * m,
+                    [&](int i, float t0, float t1) { p0[i] = t0; p1[i] = t1; pr[i] = (int32_t)r; }, unused);
+            } else {
+                int pos = 0;
+#pragma unroll
+                for (int k = 0; k < kMaxRuns; ++k) {
+                    float t = run_t[k];
+                    for (int j = 0; j < run_n[k]; ++j) {
+                        const float t1 = t + calc_dt(t, grid.cone_angle, grid.step_size, 1e10f);
+                        p0[pos] = t; p1[pos] = t1; pr[pos] = (int32_t)r;
+                        ++pos;
+                        t = t1;
+                    }
+                }
+            }
+        }
+        __syncthreads();                                     // wave_tot / block_base are reused by the next chunk
     }
 }
 
@@ -260,7 +329,7 @@ __global__ __launch_bounds__(kMarchThreads, SINGLE ? 4 : 3) void march_frame_ker
 // reservation per workgroup; the frame's sample count of the iteration rides in the high word of the same atomic.
 __global__ __launch_bounds__(kCompositeThreads) void frame_composite_kernel(
     IterPlan *plan, int n_frames, int rays_per_frame, const int32_t *__restrict__ alive_list,
-    int32_t *__restrict__ next_list, const int32_t *__restrict__ counts, const float *__restrict__ t0,
+    int32_t *__restrict__ next_list, const int32_t *__restrict__ packed, const float *__restrict__ t0,
     const float *__restrict__ t1, const float *__restrict__ sig, const float *__restrict__ rgbs, float *__restrict__ rgb,
     float *__restrict__ opacity, float *__restrict__ depth, float opc_thres)
 {
@@ -280,8 +349,8 @@ __global__ __launch_bounds__(kCompositeThreads) void frame_composite_kernel(
         int cnt = 0;
         bool alive = false;
         if (active) {
-            const int64_t sb = (int64_t)P.samp_base[f] + idx * limit;
-            cnt = counts[r];
+            const int64_t sb = packed[2 * r];
+            cnt = packed[2 * r + 1];
             float op = opacity[r];
             if (cnt > 0) {
                 const float prefix = 1.0f - op;
@@ -381,7 +450,7 @@ __global__ __launch_bounds__(256) void frame_finalize_kernel(int64_t n_rays, con
 static inline size_t align_up(size_t x) { return (x + 255) & ~(size_t)255; }
 
 struct FrameWorkspace {
-    float *t_sorted; int64_t *t_indices; uint8_t *hits; float *near; int32_t *counts;
+    float *t_sorted; int64_t *t_indices; uint8_t *hits; float *near; int32_t *packed;
     int32_t *alive_a, *alive_b;     // double-buffered list of alive ray ids
     IterPlan *plans;                // [max_iters + 1]
     float *lattice;                 // [256] first lattice point per binade (cone_angle == 0)
@@ -404,7 +473,7 @@ static FrameWorkspace carve(void *base, int64_t n, int m, int64_t cap, int max_i
     w.t_indices = (int64_t *)take((size_t)n * 2 * m * 8);
     w.hits = (uint8_t *)take((size_t)n * m);
     w.near = (float *)take((size_t)n * 4);
-    w.counts = (int32_t *)take((size_t)n * 4);
+    w.packed = (int32_t *)take((size_t)n * 8);
     w.alive_a = (int32_t *)take((size_t)n * 4);
     w.alive_b = (int32_t *)take((size_t)n * 4);
     w.plans = (IterPlan *)take((size_t)(max_iters + 2) * sizeof(IterPlan));
@@ -561,7 +630,7 @@ static int render_frames_impl(const ced_field_desc *field, int n_frames, int64_t
         const int64_t slot_bound = alive_bound + (int64_t)n_frames * kSlotAlign;
         MarchArgs M{ rays_o, rays_d, GridSpec{ binaries, aabbs, n_grids, res, step_size, cone_angle, 0, use_lattice ? W.lattice : nullptr },
                      acc, W.near, far_plane, cur_list, n_frames,
-                     (int)rays_per_frame, W.t_sorted, W.t_indices, W.hits, W.t0, W.t1, W.ridx, W.counts };
+                     (int)rays_per_frame, W.t_sorted, W.t_indices, W.hits, W.t0, W.t1, W.ridx, W.packed };
         int64_t mgrid = (slot_bound + kMarchThreads - 1) / kMarchThreads;
         if (mgrid > 8192) mgrid = 8192;
         if (n_grids == 1)
@@ -599,7 +668,7 @@ static int render_frames_impl(const ced_field_desc *field, int n_frames, int64_t
         seq = ++g_publish_seq;
         seq_of[it] = seq;
         hipLaunchKernelGGL(frame_composite_kernel, dim3((unsigned)cgrid), dim3(kCompositeThreads), 0, stream,
-                           plan, n_frames, (int)rays_per_frame, cur_list, next_list, W.counts, W.t0, W.t1, W.sigma, W.rgbs,
+                           plan, n_frames, (int)rays_per_frame, cur_list, next_list, W.packed, W.t0, W.t1, W.sigma, W.rgbs,
                            rgb, opacity, depth, opc_thres);
         hipLaunchKernelGGL(frame_schedule_kernel, dim3(1), dim3(64), 0, stream,
                            ScheduleArgs{ W.plans, it, n_frames, (int)rays_per_frame, min_samples, (int)max_samples,

@@ -131,9 +131,10 @@ class ShardedRenderer:
         self._ray_index = idx_t
         self.local_o = o[idx_t].contiguous()
         self.local_d = d[idx_t].contiguous()
-        # destination (flat ray id) of every gathered row; padded rows go to a scratch slot at the end
+        # destination (flat ray id) of every gathered row; padded rows and every rank's trailing count row go to a
+        # position outside the image (dropped by the scatter)
         n_rays = F * H * W
-        dest = np.full((self.world, self.n_pad), n_rays, np.int64)
+        dest = np.full((self.world, self.n_pad + 1), n_rays, np.int64)
         for r, s in enumerate(shards):
             dest[r, :len(s)] = s
         self.gather_index = torch.from_numpy(dest.reshape(-1)).to(o.device)
@@ -153,7 +154,12 @@ class ShardedRenderer:
         rgb, op, dp, n_samples = local
         if self.gather_index is None:
             if self.unpermute is not None:
-                rgb, op, dp = rgb[self.unpermute], op[self.unpermute], dp[self.unpermute]
+                if rgb.is_cuda:        # tile order -> raster in one HIP pass (ced_scatter_pixels)
+                    from . import ops
+                    rgb, op, dp, _ = ops.scatter_pixels(self._ray_index, F * H * W, rgb.reshape(-1, 3), op.reshape(-1, 1),
+                                                        dp.reshape(-1, 1))
+                else:
+                    rgb, op, dp = rgb[self.unpermute], op[self.unpermute], dp[self.unpermute]
             return dict(rgb=rgb.view(F, H, W, 3), opacity=op.view(F, H, W, 1), depth=dp.view(F, H, W, 1),
                         local_samples=n_samples, total_samples=n_samples)
         payload = torch.empty((self.n_pad + 1, 5), device=rgb.device, dtype=torch.float32)
@@ -175,12 +181,16 @@ class ShardedRenderer:
         total_t = (tail[:, 0] * 65536.0 + tail[:, 1]).sum()
         total = int(total_t.item()) if sync_total else None
         n_rays = F * H * W
-        image = torch.empty((n_rays + 1, 5), device=rgb.device, dtype=torch.float32)
-        image[self.gather_index] = gathered[:, :-1, :].reshape(-1, 5)
-        image = image[:n_rays]
-        return dict(rgb=image[:, 0:3].reshape(F, H, W, 3), opacity=image[:, 3:4].reshape(F, H, W, 1),
-                    depth=image[:, 4:5].reshape(F, H, W, 1), local_samples=n_samples, total_samples=total,
-                    total_samples_tensor=total_t)
+        rows = gathered.view(-1, 5)
+        if rows.is_cuda:               # the un-permute of the gathered shards: one HIP pass (ced_scatter_pixels)
+            from . import ops
+            o_rgb, o_op, o_dp, _ = ops.scatter_pixels(self.gather_index, n_rays, rows[:, 0:3], rows[:, 3:4], rows[:, 4:5])
+        else:                          # CPU tensors: the gloo tests of the sharding logic
+            image = torch.empty((n_rays + 1, 5), dtype=torch.float32)
+            image[self.gather_index] = rows
+            o_rgb, o_op, o_dp = image[:n_rays, 0:3], image[:n_rays, 3:4], image[:n_rays, 4:5]
+        return dict(rgb=o_rgb.reshape(F, H, W, 3), opacity=o_op.reshape(F, H, W, 1), depth=o_dp.reshape(F, H, W, 1),
+                    local_samples=n_samples, total_samples=total, total_samples_tensor=total_t)
 
     @torch.no_grad()
     def render(self, timestamps: torch.Tensor) -> Dict:

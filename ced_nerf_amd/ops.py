@@ -248,6 +248,20 @@ def accumulate_along_rays_(packed_info, weights, values, outputs):
     return outputs
 
 
+def reduce_along_rays(ray_indices, values, n_rays: int, weights=None, mean: bool = False):
+    """ced_reduce_along_rays: out [n_rays, C] = sum (or torch's include_self mean) of weights * values per ray."""
+    _chk(ray_indices, torch.int64, "ray_indices"); _chk(values, torch.float32, "values")
+    _chk(weights, torch.float32, "weights", allow_none=True)
+    n, c = values.shape
+    wc = 0 if weights is None else weights.shape[1]
+    out = torch.empty((n_rays, c), device=values.device, dtype=torch.float32)
+    counts = torch.empty((n_rays,), device=values.device, dtype=torch.int32) if mean else None
+    rc = _lib.lib().ced_reduce_along_rays(n, _p(ray_indices), _p(values), c, _p(weights), wc, n_rays, int(bool(mean)), _p(out),
+                                          _p(counts), _stream())
+    _lib.check(rc, "reduce_along_rays")
+    return out
+
+
 def visibility_mask(packed_info, t_starts, t_ends, sigmas, early_stop_eps, alpha_thre):
     _chk(packed_info, torch.int64, "packed_info")
     mask = torch.empty(t_starts.shape, device=t_starts.device, dtype=torch.bool)
@@ -303,6 +317,27 @@ def depth_to_u8(depth, flip_w: bool = True):
     _lib.check(_lib.lib().ced_depth_to_u8(depth.shape[0], depth.shape[1], _p(depth), int(bool(flip_w)), _p(out), _p(ws),
                                           _stream()), "depth_to_u8")
     return out
+
+
+def scatter_pixels(dest, n_pixels: int, src_rgb, src_opacity, src_depth, want_rgb8_width: int = 0, flip_w: bool = True):
+    """ced_scatter_pixels: rows (marching / gather order) -> raster images.  Sources are 2-D views whose last-dim
+    slices may be strided (e.g. columns of the gathered [rows, 5] payload).  Returns (rgb [n,3], opacity [n,1],
+    depth [n,1], rgb8 [n,3] uint8 or None)."""
+    _chk(dest, torch.int64, "dest")
+    n_rows = dest.shape[0]
+    for nm, t in (("src_rgb", src_rgb), ("src_opacity", src_opacity), ("src_depth", src_depth)):
+        assert t.is_cuda and t.dtype == torch.float32 and t.dim() == 2 and t.shape[0] == n_rows and t.stride(1) == 1, nm
+        _check_current_device(t.device.index, nm)
+    dev = dest.device
+    rgb = torch.empty((n_pixels, 3), device=dev, dtype=torch.float32)
+    opacity = torch.empty((n_pixels, 1), device=dev, dtype=torch.float32)
+    depth = torch.empty((n_pixels, 1), device=dev, dtype=torch.float32)
+    rgb8 = torch.empty((n_pixels, 3), device=dev, dtype=torch.uint8) if want_rgb8_width else None
+    rc = _lib.lib().ced_scatter_pixels(n_rows, _p(src_rgb), src_rgb.stride(0), _p(src_opacity), src_opacity.stride(0),
+                                       _p(src_depth), src_depth.stride(0), _p(dest), n_pixels, _p(rgb), _p(opacity),
+                                       _p(depth), _p(rgb8), int(want_rgb8_width), int(bool(flip_w)), _stream())
+    _lib.check(rc, "scatter_pixels")
+    return rgb, opacity, depth, rgb8
 
 
 def weight_grad(x, dy):

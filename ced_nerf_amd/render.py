@@ -13,25 +13,28 @@ from .nerfacc_api import (_packed_info_from, accumulate_along_rays, render_trans
 
 def reduce_along_rays(ray_indices: Tensor, values: Tensor, n_rays: Optional[int] = None,
                       weights: Optional[Tensor] = None, reduce: str = "mean") -> Tensor:
-    """cednerf/render.py:8-39 (training extras; plain torch in the reference as well)."""
+    """cednerf/render.py:8-39: per-ray scatter_reduce_ of weights * values (the training extras of `rendering`,
+    render.py:101-124), on the HIP kernel ced_reduce_along_rays.  Same asserts and error behaviour as the reference."""
     assert ray_indices.dim() == 1 and values.dim() == 2
     if not values.is_cuda:
         raise NotImplementedError("Only support cuda inputs.")
     if weights is not None:
         assert values.dim() == 2 and values.shape[0] == weights.shape[0], \
             "Invalid shapes: {} vs {}".format(values.shape, weights.shape)
-        src = weights * values
-    else:
-        src = values
     if ray_indices.numel() == 0:
         assert n_rays is not None
-        return torch.zeros((n_rays, src.shape[-1]), device=values.device)
+        return torch.zeros((n_rays, values.shape[-1]), device=values.device)
     if n_rays is None:
         n_rays = int(ray_indices.max()) + 1
-    index = ray_indices.long()[:, None].expand(-1, src.shape[-1])
-    outputs = torch.zeros((n_rays, src.shape[-1]), device=values.device, dtype=src.dtype)
-    outputs.scatter_reduce_(0, index, src, reduce=reduce)
-    return outputs
+    if reduce not in ("sum", "mean"):
+        raise NotImplementedError(f"reduce={reduce!r}: the reference uses 'mean' (default) and 'sum'")
+    w = None
+    if weights is not None:
+        w = weights.float().reshape(weights.shape[0], -1).contiguous()
+        if w.shape[1] not in (1, values.shape[1]):
+            w = w.expand(-1, values.shape[1]).contiguous()
+    return ops.reduce_along_rays(ray_indices.long().contiguous(), values.float().contiguous(), int(n_rays), w,
+                                 mean=(reduce == "mean"))
 
 
 def render_weight_from_density_prefix(t_starts: Tensor, t_ends: Tensor, sigmas: Tensor, prefix_trans: Tensor,

@@ -228,6 +228,16 @@ int ced_render_weights(int64_t n_rays, const int64_t *packed_info, const float *
 int ced_accumulate_along_rays(int64_t n_rays, const int64_t *packed_info, const float *weights,
                               const float *values, int32_t n_channels, float *out, void *stream);
 
+/* reduce_along_rays(ray_indices, values, n_rays, weights, reduce) -- cednerf/render.py:8-39 (the training extras of
+ * rendering(), render.py:101-124): out [n_rays, C] = scatter_reduce_ of weights * values into zeros, reduce "sum"
+ * (mean == 0) or "mean" (mean == 1, with the initial zero counted as an element, torch's include_self default).
+ * values [S, C]; weights NULL or [S, weight_channels] with weight_channels 1 (broadcast) or C; ray indices outside
+ * [0, n_rays) are ignored; counts_workspace: n_rays int32 of device scratch (mean only).  Float atomics, as in torch:
+ * sums of unsorted indices depend on arrival order in the last bits. */
+int ced_reduce_along_rays(int64_t n_samples, const int64_t *ray_indices, const float *values, int32_t n_channels,
+                          const float *weights, int32_t weight_channels, int64_t n_rays, int32_t mean, float *out,
+                          int32_t *counts_workspace, void *stream);
+
 /* nerfacc.render_visibility_from_density inside OccGridEstimator.sampling (cednerf/utils.py:115-125):
  * mask[i] = trans_i >= early_stop_eps && (alpha_thre <= 0 || alpha_i >= alpha_thre). */
 int ced_visibility_mask(int64_t n_rays, const int64_t *packed_info, const float *t_starts,
@@ -265,6 +275,17 @@ int ced_composite_backward(int64_t n_rays, const int64_t *packed_info, const flo
 int ced_frame_to_rgb8(int32_t height, int32_t width, const float *rgb, int32_t flip_w, uint8_t *out, void *stream);
 int ced_depth_to_u8(int32_t height, int32_t width, const float *depth, int32_t flip_w, uint8_t *out,
                     void *workspace, void *stream);
+
+/* The exchange's consumer ("a local un-permute fused into the consumer"): rendered pixels arrive in marching
+ * order (8x8-tile order; with several GPUs every rank's shard of it, all-gathered as [rows, 5] = rgb, opacity, depth);
+ * row i goes to raster pixel dest[i] (rows with dest outside [0, n_pixels) are padding).  One pass writes the raster
+ * rgb [n_pixels,3] / opacity [n_pixels] / depth [n_pixels] (each may be NULL) and, when rgb8 != NULL, the 8-bit
+ * colour frame of ced_frame_to_rgb8 directly ([n_pixels,3] uint8, flipped inside rows of `width` pixels when flip_w).
+ * Sources are given with their row strides in floats (5, 5, 5 for the gathered payload; 3, 1, 1 for separate arrays). */
+int ced_scatter_pixels(int64_t n_rows, const float *src_rgb, int32_t stride_rgb, const float *src_opacity,
+                       int32_t stride_opacity, const float *src_depth, int32_t stride_depth, const int64_t *dest,
+                       int64_t n_pixels, float *rgb, float *opacity, float *depth, uint8_t *rgb8, int32_t width,
+                       int32_t flip_w, void *stream);
 
 int64_t ced_weight_grad_workspace_bytes(int64_t n, int32_t n_out, int32_t n_in);
 int ced_weight_grad(int64_t n, const float *x, int32_t n_in, const float *dy, int32_t n_out, float *dw,

@@ -985,6 +985,95 @@ def test_frame_to_uint8_bitexact(oracle):
         ops.frame_to_rgb8(torch.zeros(4, 4, 3))
 
 
+def test_reduce_along_rays_matches_scatter_reduce(oracle):
+    """a5: cednerf/render.py:8-39 on the HIP kernel, against torch's own scatter_reduce_ on the CPU (the statement the
+    reference makes) and a float64 numpy sum: ray-packed and shuffled indices, sum and mean, broadcast and per-channel
+    weights, empty rays, empty input, n_rays inferred."""
+    from ced_nerf_amd.render import reduce_along_rays
+    rng = np.random.default_rng(9)
+    n_rays, C = 700, 5
+    counts = rng.integers(0, 40, size=n_rays); counts[::7] = 0
+    ri = np.repeat(np.arange(n_rays), counts).astype(np.int64)
+    S = ri.shape[0]
+    vals = rng.normal(size=(S, C)).astype(np.float32)
+    w1 = rng.uniform(0, 1, size=(S, 1)).astype(np.float32)
+    for shuffle in (False, True):
+        order = rng.permutation(S) if shuffle else np.arange(S)
+        r_, v_, w_ = ri[order], vals[order], w1[order]
+        for reduce in ("sum", "mean"):
+            for w in (None, w_, np.repeat(w_, C, axis=1)):
+                got = N(reduce_along_rays(T(r_), T(v_), n_rays, None if w is None else T(w), reduce=reduce))
+                src = v_ if w is None else w * v_
+                ref = torch.zeros((n_rays, C)).scatter_reduce_(0, torch.from_numpy(r_)[:, None].expand(-1, C), torch.from_numpy(src),
+                                                               reduce=reduce).numpy()
+                acc = np.zeros((n_rays, C)); np.add.at(acc, r_, src.astype(np.float64))
+                if reduce == "mean":
+                    acc = acc / (counts[:, None] + 1)
+                assert got.shape == (n_rays, C)
+                assert np.abs(got - acc).max() <= 2e-5 and np.abs(got - ref).max() <= 2e-5, (shuffle, reduce)
+    assert reduce_along_rays(T(ri[:0]), T(vals[:0]), 9).shape == (9, C)
+    assert N(reduce_along_rays(T(ri[:0]), T(vals[:0]), 9)).sum() == 0
+    assert reduce_along_rays(T(ri), T(vals), None, reduce="sum").shape == (int(ri.max()) + 1, C)
+    with pytest.raises(AssertionError):
+        reduce_along_rays(T(ri), T(vals), n_rays, T(w1[:-1]))
+
+
+def test_checkpoint_round_trip_renders_the_same_frame(oracle):
+    """f3 (train_real.py:433-441,524-529): torch.save({"radiance_field": sd, "occupancy_grid": sd}) -> fresh modules ->
+    load_state_dict -> the frame renders bit-identically; the estimator state keys are nerfacc's."""
+    import io
+    from ced_nerf_amd.model import DNGPradianceField
+    from ced_nerf_amd.nerfacc_api import OccGridEstimator
+    from ced_nerf_amd.utils import render_image_test
+    sc = _scene("hypernerf", 48, 64, "trained", log2_hashmap_size=15)
+    of, oest, f, est, rays, rk = _setup(oracle, sc)
+    cfg = sc["cfg"]
+    ts = T(sc["timestamps"])
+    want = render_image_test(1024, f, est, rays, timestamps=ts, **rk)
+    buf = io.BytesIO()
+    torch.save({"radiance_field": f.state_dict(), "occupancy_grid": est.state_dict()}, buf)
+    buf.seek(0)
+    ck = torch.load(buf, map_location=DEV)
+    assert set(ck["occupancy_grid"]) == {"resolution", "aabbs", "occs", "binaries"}
+    f2 = DNGPradianceField(aabb=cfg["aabb"], dst_resolution=cfg["hash_max_res"], log2_hashmap_size=15,
+                           moving_step=cfg["moving_step"], seed=11, **cfg["flags"]).to(DEV).eval()
+    est2 = OccGridEstimator(cfg["aabb"], cfg["grid_resolution"], cfg["grid_levels"]).to(DEV)
+    before = render_image_test(1024, f2, est2, rays, timestamps=ts, **rk)          # empty grid, random weights
+    assert before[3] == 0
+    f2.load_state_dict(ck["radiance_field"]); est2.load_state_dict(ck["occupancy_grid"])
+    got = render_image_test(1024, f2, est2, rays, timestamps=ts, **rk)
+    assert got[3] == want[3] and want[3] > 1000
+    for a, b in zip(got[:3], want[:3]):
+        assert torch.equal(a, b)
+
+
+def test_scatter_pixels_unpermutes_and_converts(oracle):
+    """ced_scatter_pixels: rows in marching / gather order -> raster images, padding rows dropped, and the 8-bit colour
+    frame of train_real.py:556 in the same pass (bit-exact against numpy)."""
+    from ced_nerf_amd import ops
+    rng = np.random.default_rng(4)
+    H, W, F = 12, 20, 2
+    n = F * H * W
+    perm = rng.permutation(n)
+    rows = rng.uniform(-0.1, 1.1, size=(n + 7, 5)).astype(np.float32)
+    dest = np.concatenate([perm, np.full(7, n)]).astype(np.int64)          # 7 padding rows
+    order = rng.permutation(n + 7)                                         # padding anywhere in the payload
+    rows, dest = rows[order], dest[order]
+    G = T(rows)
+    rgb, op, dp, rgb8 = ops.scatter_pixels(T(dest), n, G[:, 0:3], G[:, 3:4], G[:, 4:5], want_rgb8_width=W, flip_w=True)
+    want = np.zeros((n, 5), np.float32)
+    keep = dest < n
+    want[dest[keep]] = rows[keep]
+    assert_bitexact(N(rgb), want[:, 0:3], "rgb"); assert_bitexact(N(op), want[:, 3:4], "opacity"); assert_bitexact(N(dp), want[:, 4:5], "depth")
+    img = want[:, 0:3].reshape(F, H, W, 3)
+    want8 = np.flip(np.clip(img * 255, 0, 255), axis=2).astype(np.uint8)
+    assert np.array_equal(N(rgb8).reshape(F, H, W, 3), want8)
+    # separate source arrays (strides 3, 1, 1): the single-GPU tile-order path
+    a, b, c = T(rows[:, 0:3].copy()), T(rows[:, 3:4].copy()), T(rows[:, 4:5].copy())
+    rgb2, op2, dp2, none8 = ops.scatter_pixels(T(dest), n, a, b, c)
+    assert none8 is None and torch.equal(rgb2, rgb) and torch.equal(op2, op) and torch.equal(dp2, dp)
+
+
 def test_render_video_equals_frames_rendered_alone(oracle):
     """video.render_video: a camera path with per-frame times streamed through frames in flight, rays generated on
     the device on each lane's stream; every frame equals render_image_test of that frame alone, and the uint8 frames
@@ -1171,7 +1260,7 @@ def test_bench_two_rank_rehearsal():
     env = dict(os.environ, CED_BENCH_BACKEND="gloo")
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
            "--master-port", str(free_port()), os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1",
-           "--width", "256", "--height", "256", "--no-cpu-baseline", "--also", "f16x2"]
+           "--width", "256", "--height", "256", "--no-cpu-baseline", "--also", "f16x2", "--min-seconds", "0.2"]
     out = subprocess.run(cmd, cwd=root, env=env, capture_output=True, text=True, timeout=600)
     assert out.returncode == 0, out.stderr[-2000:]
     lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
@@ -1180,6 +1269,28 @@ def test_bench_two_rank_rehearsal():
     assert d["n_gpus"] == 2 and d["steps"] == 2 and d["scaling"] == "weak" and d["value"] > 0
     assert d["config"]["frames_per_step"] == 18 and d["config"]["frames_per_call"] == 3 and "f16x2" in d["other_mlp_precisions"]
     assert d["roofline"]["bound"] == "mfma" and 0 < d["roofline"]["frac"] < 1
+    # the gathered frames equal the frames rendered whole by one rank: schedule-local counts, pixels within 1e-4 except
+    # the rare ray whose sample set changes with the restart points of its march (bench.py, gather_check)
+    g = d["gather_check"]
+    assert g["frames"] == 3 and g["ok"], g
+    assert g["pixels_over_1e-4"] <= 4 and g["rgb_max_abs"] <= 5e-3 and g["samples_single_rank"] > 10000
+    w = d["windows"]
+    assert w["n"] >= 5 and w["p10"] <= w["median"] <= w["p90"] and w["steps_each"] == 2
+
+
+def test_bench_two_rank_rehearsal_strong_scaling():
+    """The same launch line with --scaling strong: total work fixed, a unit = one rank's share of ONE frame."""
+    import json, os, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, CED_BENCH_BACKEND="gloo")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", str(free_port()), os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1",
+           "--width", "256", "--height", "256", "--no-cpu-baseline", "--also", "", "--scaling", "strong", "--min-seconds", "0.2"]
+    out = subprocess.run(cmd, cwd=root, env=env, capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stderr[-2000:]
+    d = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][0])
+    assert d["n_gpus"] == 2 and d["scaling"] == "strong" and d["config"]["frames_per_step"] == 9
+    assert d["gather_check"]["ok"], d["gather_check"]
 
 
 @pytest.mark.parametrize("case", [0, 3])
