@@ -2,7 +2,7 @@
 
 One frame = one full-frame `render_image_test` (cednerf/utils.py:153-318) of the BASELINE.json
 config-2 workload: 800x800 D-NeRF "lego"-shaped synthetic scene, hash L=16 F=2 T=2^21 fp32 table,
-64-wide MLPs, "trained-like" parameters, max_samples=1024.  A step renders 3 calls in flight x 3 frames
+64-wide MLPs, "trained-like" parameters, max_samples=1024.  A step renders 3 calls in flight x 8 frames
 per call x N GPUs such frames (consecutive camera azimuths of a video render), every frame on its own
 render_image_test schedule; with N GPUs their rays are dealt tile-cyclically over the ranks and the pixels
 are all-gathered over RCCL, so per-GPU work is fixed (weak scaling).
@@ -53,7 +53,7 @@ def parse():
                     help="per-launch HBM traffic of the field kernel from the rocprofv3 --pmc passes (tools/pmc_summary.py)")
     ap.add_argument("--regime", default="trained")
     ap.add_argument("--max-samples", type=int, default=1024)
-    ap.add_argument("--frames-per-call", type=int, default=int(os.environ.get("CED_FRAMES_PER_CALL", "3")),
+    ap.add_argument("--frames-per-call", type=int, default=int(os.environ.get("CED_FRAMES_PER_CALL", "8")),
                     help="frames rendered by one native call (ced_render_frames_test): they share the launches of an "
                          "iteration, each on its own schedule; 1 = ced_render_image_test per frame")
     ap.add_argument("--frames-in-flight", type=int, default=3,
@@ -219,7 +219,7 @@ def main():
         lane_renderers.append(r)
     # multi-rank: the pixel all-gather of one step overlaps the next step's kernels (own stream, no read-back)
     renderer = cdist.PipelinedRenderer(lane_renderers, async_gather=world > 1,
-                                       field_max_blocks=int(os.environ.get("CED_FIELD_MAX_BLOCKS", "128")))
+                                       field_max_blocks=int(os.environ.get("CED_FIELD_MAX_BLOCKS", "256")))
     field_ms, field_launches, field_samples = [0.0], [0], [0]
     step_no = [0]
 

@@ -14,7 +14,7 @@ _PKG = os.path.dirname(os.path.abspath(__file__))
 _ROOT = os.path.dirname(_PKG)
 LIB_PATH = os.environ.get("CED_NERF_LIB", os.path.join(_PKG, "libcednerf_hip.so"))
 SOURCES = ["runtime.hip", "march.hip", "composite.hip", "field.hip", "field_half.hip", "frame.hip", "occgrid.hip",
-           "raygen.hip", "wgrad.hip", "pixels.hip", "accel.hip"]
+           "raygen.hip", "wgrad.hip", "pixels.hip", "accel.hip", "linear.hip"]
 MLP_F32, MLP_F16X2, MLP_F16 = 0, 1, 2          # ced_field_desc.mlp_precision
 MLP_PRECISIONS = {"f32": MLP_F32, "f16x2": MLP_F16X2, "f16": MLP_F16}
 HIPCC_FLAGS = ["--offload-arch=gfx950", "-O3", "-ffp-contract=off", "-fPIC", "-shared", "-std=c++17"]
@@ -86,6 +86,7 @@ PROTOTYPES = {
     "ced_frame_to_rgb8": (C.c_int, [_i32, _i32, _vp, _i32, _vp, _vp]),
     "ced_depth_to_u8": (C.c_int, [_i32, _i32, _vp, _i32, _vp, _vp, _vp]),
     "ced_scatter_pixels": (C.c_int, [_i64, _vp, _i32, _vp, _i32, _vp, _i32, _vp, _i64, _vp, _vp, _vp, _vp, _i32, _i32, _vp]),
+    "ced_linear": (C.c_int, [_i64, _vp, _i32, _vp, _i32, _i32, _i32, _i32, _i32, _vp, _vp, _vp]),
     "ced_weight_grad_workspace_bytes": (_i64, [_i64, _i32, _i32]),
     "ced_weight_grad": (C.c_int, [_i64, _vp, _i32, _vp, _i32, _vp, _vp, _i64, _vp]),
     "ced_composite_step": (C.c_int, [_i64, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _f, _i32, _vp, _vp, _vp]),

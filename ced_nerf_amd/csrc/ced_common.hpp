@@ -92,6 +92,22 @@ __device__ __forceinline__ float det_sinpi_phase(float y, int phase)
     float x = 3.14159274101257324f * r;
     return quadrant_select((((int)n) & 3) + phase, x);
 }
+// Both phases of one Frequency term at once: p0 = sin(pi*y), p1 = sin(pi*y + pi/2) -- the same reduction, the same two
+// polynomials and the same selection as det_sinpi_phase(y, 0) and det_sinpi_phase(y, 1), evaluated once.
+__device__ __forceinline__ void det_sinpi_both(float y, float &p0, float &p1)
+{
+    float n = __builtin_rintf(y + y);
+    float r = y - 0.5f * n;
+    float x = 3.14159274101257324f * r;
+    const float s = sin_kernel(x), c = cos_kernel(x);
+    const int q = ((int)n) & 3;
+    const float v0 = (q & 1) ? c : s;
+    p0 = (q & 2) ? -v0 : v0;
+    const int q1 = q + 1;
+    const float v1 = (q1 & 1) ? c : s;
+    p1 = (q1 & 2) ? -v1 : v1;
+}
+
 // sin(x), two-step Cody-Waite reduction by pi/2
 __device__ __forceinline__ float det_sinf(float x)
 {

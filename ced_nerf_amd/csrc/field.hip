@@ -224,25 +224,48 @@ __global__ __launch_bounds__(THREADS) void field_kernel(FieldArgs A)
         float B[NT][16];
         f4 D[NT][4];
 
-        // --- tcnn Frequency(4) on (x,y,z,t): feature k = 8*dim + 2*freq + phase, k = 4S+g ---
+        // --- tcnn Frequency(4) on (x,y,z,t): feature k = 8*dim + 2*freq + phase, k = 4S+g, i.e. k-step S of lane group g
+        // is dimension S>>1, frequency 2(S&1) + (g>>1), phase g&1.  Lane groups g and g^1 need the same terms in the two
+        // phases, and one evaluation yields both (det_sinpi_both): the even group evaluates one k-step of a pair, the
+        // odd group the other, and a single v_permlane16_swap hands each its partner's half -- swap(p0, p1) leaves the
+        // even group's k-step in the first register and the odd group's in the second, each lane seeing its own phase.
+        // Pairs: (S0 | S2) and (S1 | S3) = x | y at the two frequencies, (S4 | S5) = z at both, (S6 | S7) = t at both. ---
 #pragma unroll
         for (int j = 0; j < NT; ++j) {
+#ifdef CED_FIELD_SKELETON
+#pragma unroll
+            for (int S = 0; S < 8; ++S) B[j][S] = (S < 6 ? px[j][S >> 1] : tq[j]) * (float)(1 << (2 * (S & 1) + (g >> 1)));
+#elif defined(CED_AB_NO_FREQ_SPLIT)
 #pragma unroll
             for (int S = 0; S < 8; ++S) {
-                const int dim = S >> 1;
-                if (dim == 3 && shared_time) {           // eval frames: one timestamp for every sample
-                    B[j][S] = t_feat[S - 6];
-                    continue;
-                }
-                const float v = (dim < 3) ? px[j][dim < 3 ? dim : 0] : tq[j];
-                const int f = 2 * (S & 1) + (g >> 1);
-                const float y = v * (float)(1 << f);
-#ifdef CED_FIELD_SKELETON
-                B[j][S] = y;
-#else
-                B[j][S] = det_sinpi_phase(y, g & 1);
-#endif
+                if ((S >> 1) == 3 && shared_time) { B[j][S] = t_feat[S - 6]; continue; }
+                const float v = ((S >> 1) < 3) ? px[j][(S >> 1) < 3 ? (S >> 1) : 0] : tq[j];
+                B[j][S] = det_sinpi_phase(v * (float)(1 << (2 * (S & 1) + (g >> 1))), g & 1);
             }
+#else
+            const bool odd = (g & 1) != 0;
+            const float sc0 = (float)(1 << (g >> 1)), sc1 = 4.0f * sc0;           // 2^f for the pair's two frequencies
+            const float vxy = odd ? px[j][1] : px[j][0];
+            float p0, p1;
+            det_sinpi_both(vxy * sc0, p0, p1);
+            auto sw = __builtin_amdgcn_permlane16_swap(__float_as_uint(p0), __float_as_uint(p1), false, false);
+            B[j][0] = __uint_as_float(sw[0]); B[j][2] = __uint_as_float(sw[1]);
+            det_sinpi_both(vxy * sc1, p0, p1);
+            sw = __builtin_amdgcn_permlane16_swap(__float_as_uint(p0), __float_as_uint(p1), false, false);
+            B[j][1] = __uint_as_float(sw[0]); B[j][3] = __uint_as_float(sw[1]);
+            const float scz = odd ? sc1 : sc0;
+            det_sinpi_both(px[j][2] * scz, p0, p1);
+            sw = __builtin_amdgcn_permlane16_swap(__float_as_uint(p0), __float_as_uint(p1), false, false);
+            B[j][4] = __uint_as_float(sw[0]); B[j][5] = __uint_as_float(sw[1]);
+            if (shared_time) {                           // eval frames: one timestamp for every sample
+                B[j][6] = t_feat[0];
+                B[j][7] = t_feat[1];
+            } else {
+                det_sinpi_both(tq[j] * scz, p0, p1);
+                sw = __builtin_amdgcn_permlane16_swap(__float_as_uint(p0), __float_as_uint(p1), false, false);
+                B[j][6] = __uint_as_float(sw[0]); B[j][7] = __uint_as_float(sw[1]);
+            }
+#endif
         }
         // --- motion MLP 32-64-64-64-(3|6) ---
         mlp_layer<8, 4, NT>(lw + BL::M0, lane, B, D);

@@ -81,10 +81,16 @@ __device__ __forceinline__ void hash_level(const LevelConst &L, const void *__re
     float fr[3], om[3];
 #pragma unroll
     for (int a = 0; a < 3; ++a) {
-        float p = x[a] * L.scale + 0.5f;
-        float fl = __builtin_floorf(p);
+        // p >= 0.5: the conversion truncates = floor, and p - floor(p) is exact, which is what v_fract_f32 returns
+        const float p = x[a] * L.scale + 0.5f;
+#ifdef CED_AB_NO_FRACT
+        const float fl = __builtin_floorf(p);
         g[a] = (uint32_t)fl;
         fr[a] = p - fl;
+#else
+        g[a] = (uint32_t)p;
+        fr[a] = __builtin_amdgcn_fractf(p);
+#endif
         om[a] = 1.0f - fr[a];
     }
     // byte strides: x is the entry size (a power of two: a shift); dense levels have res^2 * EB < 2^24, so

@@ -340,6 +340,22 @@ def scatter_pixels(dest, n_pixels: int, src_rgb, src_opacity, src_depth, want_rg
     return rgb, opacity, depth, rgb8
 
 
+def linear(x, w, transpose_w: bool = False, relu: bool = False, mask=None):
+    """ced_linear: y = x w^T (w [n_out, n_in]) or, transpose_w, y = x w (w [n_in, n_out]); optional ReLU on the result
+    and optional mask (y *= mask > 0, the fused ReLU derivative of the layer below)."""
+    _chk(x, torch.float32, "x"); _chk(w, torch.float32, "w"); _chk(mask, torch.float32, "mask", allow_none=True)
+    assert x.dim() == 2 and w.dim() == 2
+    n, n_in = x.shape
+    n_out = w.shape[1] if transpose_w else w.shape[0]
+    if mask is not None:
+        assert mask.shape == (n, n_out), f"mask {tuple(mask.shape)} vs output {(n, n_out)}"
+    y = torch.empty((n, n_out), device=x.device, dtype=torch.float32)
+    rc = _lib.lib().ced_linear(n, _p(x), n_in, _p(w), w.shape[0], w.shape[1], int(bool(transpose_w)), n_out, int(bool(relu)),
+                               _p(mask), _p(y), _stream())
+    _lib.check(rc, "linear")
+    return y
+
+
 def weight_grad(x, dy):
     """ced_weight_grad: dW [n_out, n_in] = dy^T x over the sample stream (x [S, n_in], dy [S, n_out], fp32)."""
     _chk(x, torch.float32, "x"); _chk(dy, torch.float32, "dy")

@@ -1,13 +1,14 @@
-"""Training-time field and step: first end-to-end slice of the training path.
+"""Training-time field and step: the training path.
 
-What runs where, for now:
+What runs where:
   * sampling (occupancy-grid marching, stratified)            -> HIP  (nerfacc_api.OccGridEstimator.sampling)
   * hash-grid encode, forward and backward                    -> HIP  (ced_hash_encode / ced_hash_encode_backward)
   * compositing, forward and backward                         -> HIP  (render.rendering_train)
   * gradient-free densities of the sampling pass               -> HIP  (the fused inference kernel on the shared parameters)
-  * the three bias-free MLPs: y = x W^T and dx = dy W         -> plain library GEMMs through torch (rocBLAS);
-    dW = dy^T x (tiny tile, million-deep reduction)           -> HIP  (ced_weight_grad, csrc/wgrad.hip).
-    The fused forward kernel of model.py has no backward yet.  Encodings and the small element-wise pieces are torch.
+  * the bias-free MLPs (motion, base, head, prediction heads) -> HIP  in both directions, no library GEMM:
+    y = relu(x W^T) and dx = (dz W) * relu' through ced_linear (csrc/linear.hip), dW = dz^T x through ced_weight_grad
+    (csrc/wgrad.hip); `_MlpFn` strings them into one autograd node per MLP.
+    Encodings and the small element-wise pieces (sin, exp, sigmoid, huber) are torch element-wise kernels.
 `TrainableField` keeps the parameter names and layout of `DNGPradianceField` (hash_table, xyz_wrap, mlp_base,
 mlp_head as W[out][in]), so `to_inference()` hands the trained weights to the fused kernels unchanged, and
 `tests/test_gpu_parity.py` checks that the two forwards agree.  Mirrors cednerf/model.py:354-488 (forward) and the
@@ -48,9 +49,42 @@ class _HashFn(torch.autograd.Function):
         return dx, grad_table, None
 
 
+class _MlpFn(torch.autograd.Function):
+    """A bias-free ReLU MLP (linear last layer) as ONE autograd node on the HIP kernels: forward y_l = relu(y_{l-1} W_l^T)
+    through ced_linear; backward dW_l = dz_l^T y_{l-1} through ced_weight_grad and dz_{l-1} = (dz_l W_l) * [y_{l-1} > 0]
+    through ced_linear with the ReLU derivative fused.  No library GEMM (tcnn FullyFusedMLP forward/backward,
+    cednerf/model.py:200-222,280-344)."""
+
+    @staticmethod
+    def forward(ctx, x, *weights):
+        h = x.detach().float().contiguous()
+        acts = [h]
+        ws = [w.detach().float().contiguous() for w in weights]
+        for i, w in enumerate(ws):
+            h = ops.linear(h, w, relu=i < len(ws) - 1)
+            acts.append(h)
+        ctx.save_for_backward(*acts[:-1], *ws)
+        ctx.n_layers = len(ws)
+        return h
+
+    @staticmethod
+    def backward(ctx, dy):
+        n = ctx.n_layers
+        acts, ws = ctx.saved_tensors[:n], ctx.saved_tensors[n:]
+        dz = dy.float().contiguous()
+        grads = [None] * n
+        for l in reversed(range(n)):
+            if ctx.needs_input_grad[1 + l]:
+                grads[l] = ops.weight_grad(acts[l], dz)
+            if l > 0 or ctx.needs_input_grad[0]:
+                # acts[l] is the (post-ReLU) output of layer l-1: its positive entries are where the gradient passes
+                dz = ops.linear(dz, ws[l], transpose_w=True, mask=acts[l] if l > 0 else None)
+        return (dz if ctx.needs_input_grad[0] else None, *grads)
+
+
 class _LinearFn(torch.autograd.Function):
-    """y = x W^T of a bias-free layer.  The weight gradient dW = dy^T x -- a 64x64 tile reduced over ~1e6 samples,
-    which a library GEMM runs on a handful of workgroups -- goes through ced_weight_grad; y and dx stay library GEMMs."""
+    """One bias-free layer through the library (torch -> rocBLAS) for y and dx: kept ONLY as the A/B reference of the
+    tests (`TrainableField.hip_mlp = False`); the training path itself uses `_MlpFn`."""
 
     @staticmethod
     def forward(ctx, x, w):
@@ -65,10 +99,17 @@ class _LinearFn(torch.autograd.Function):
         return dx, dw
 
 
+def _frequency4(v: torch.Tensor) -> torch.Tensor:
+    """tcnn Frequency(n_frequencies=4) on [N, D]: [dim][freq][sin, cos] of pi * 2^k * v."""
+    ang = math.pi * v[:, :, None] * (2.0 ** torch.arange(4, device=v.device, dtype=torch.float32))
+    return torch.stack([torch.sin(ang), torch.sin(ang + 0.5 * math.pi)], dim=-1).reshape(v.shape[0], 8 * v.shape[1])
+
+
 class TrainableField(torch.nn.Module):
     """Differentiable DNGPradianceField (cednerf/model.py:97-488) with the inference module's parameters."""
 
-    def __init__(self, params: Dict, device="cuda"):
+    def __init__(self, params: Dict, device="cuda", use_feat_predict: bool = False, use_weight_predict: bool = False,
+                 seed: int = 0):
         super().__init__()
         h = params["hash"]
         if h.get("temporal", False) or np.asarray(h["table"]).dtype != np.float32:
@@ -89,29 +130,41 @@ class TrainableField(torch.nn.Module):
             from .encoder import SinusoidalEncoder, SinusoidalEncoderWithExp
             self.time_encoder = SinusoidalEncoder(1, 0, 4, True)
             self.time_encoder_feat = SinusoidalEncoderWithExp(1, 0, 4, True)
+        # the training-only prediction heads (cednerf/model.py:312-344): Frequency(4) on (x_move, t) -> 64 -> 32 / 1
+        self.use_feat_predict, self.use_weight_predict = bool(use_feat_predict), bool(use_weight_predict)
+        gen = torch.Generator().manual_seed(seed)
 
-    hip_weight_grad = True          # False: all three GEMMs of a layer through the library (A/B timing, tests)
+        def xavier(o, i):
+            lim = math.sqrt(6.0 / (i + o))
+            return torch.nn.Parameter(torch.empty(o, i).uniform_(-lim, lim, generator=gen).to(device))
+        if self.use_feat_predict:
+            self.mlp_feat_prediction = torch.nn.ParameterList([xavier(64, 32), xavier(2 * h["n_levels"], 64)])
+        if self.use_weight_predict:
+            self.mlp_weight_prediction = torch.nn.ParameterList([xavier(64, 32), xavier(1, 64)])
+
+    hip_mlp = True                  # False: the layers' y and dx through the library (A/B reference of the tests)
+    hip_weight_grad = True          # (with hip_mlp False) False: dW through the library as well
 
     def _mlp(self, x, weights):
+        if self.hip_mlp:
+            return _MlpFn.apply(x, *weights)
         lin = _LinearFn.apply if self.hip_weight_grad else (lambda a, w: a @ w.t())
         for w in weights[:-1]:
             x = torch.relu(lin(x, w))
         return lin(x, weights[-1])
 
-    def forward(self, positions: torch.Tensor, t: torch.Tensor, directions: torch.Tensor):
-        """positions [N,3] world, t [N,1] in [0,1], directions [N,3] -> (rgb [N,3], sigma [N])."""
+    def forward(self, positions: torch.Tensor, t: torch.Tensor, directions: torch.Tensor, return_internal: bool = False):
+        """positions [N,3] world, t [N,1] in [0,1], directions [N,3] -> (rgb [N,3], sigma [N]); with return_internal
+        also the dict of cednerf/model.py:428-443 (`move`, `selector`, `latent_losses`, `weight_losses`)."""
         x, tt = positions.float(), t.reshape(-1, 1).float()
-        # tcnn Frequency(4) on (x,y,z,t): [dim][freq][sin,cos] of pi * 2^k * v  (SURVEY A.7)
-        v = torch.cat([x, tt], dim=-1)                                             # [N,4]
-        ang = math.pi * v[:, :, None] * (2.0 ** torch.arange(4, device=x.device, dtype=torch.float32))   # [N,4,4]
-        enc = torch.stack([torch.sin(ang), torch.sin(ang + 0.5 * math.pi)], dim=-1).reshape(x.shape[0], 32)
+        enc = _frequency4(torch.cat([x, tt], dim=-1))                               # [N,32]
         mo = self._mlp(enc, list(self.xyz_wrap))
         move = mo[:, :3] * self.moving_step                                         # model.py:356-363
         if self.use_div_offsets:
             move = move + torch.tanh(mo[:, 3:6]) * self.moving_step
         xn = (x + move - self.aabb[:3]) / (self.aabb[3:] - self.aabb[:3])           # model.py:378-379
         selector = ((xn > 0.0) & (xn < 1.0)).all(dim=-1)                            # model.py:383
-        feat = _HashFn.apply(xn.clamp(0.0, 1.0), self.hash_table, self.hash_cfg)
+        hash_feat = feat = _HashFn.apply(xn.clamp(0.0, 1.0), self.hash_table, self.hash_cfg)
         if self.time_mode:                                                          # model.py:386-403
             mn = move.norm(dim=-1, keepdim=True)
             te = self.time_encoder(tt) if self.time_mode == 1 else self.time_encoder_feat(tt, mn)
@@ -124,7 +177,18 @@ class TrainableField(torch.nn.Module):
         sh = torch.stack([torch.full_like(w[:, 0], 0.28209479177387814), -0.48860251190291987 * w[:, 1],
                           0.48860251190291987 * w[:, 2], -0.48860251190291987 * w[:, 0]], dim=-1)
         rgb = torch.sigmoid(self._mlp(torch.cat([sh, bout[:, 1:]], dim=-1), list(self.mlp_head)))
-        return rgb, sigma
+        if not return_internal:
+            return rgb, sigma
+        internal = {"move": move, "selector": selector}                              # model.py:428-443
+        if self.use_feat_predict or self.use_weight_predict:
+            temp = _frequency4(torch.cat([xn, tt], dim=-1))
+            if self.use_feat_predict:
+                predict_feat = self._mlp(temp, list(self.mlp_feat_prediction))
+                internal["latent_losses"] = torch.nn.functional.huber_loss(predict_feat, hash_feat, reduction="none") \
+                    * selector[:, None].to(predict_feat.dtype)
+            if self.use_weight_predict:
+                internal["weight_losses"] = self._mlp(temp, list(self.mlp_weight_prediction))
+        return rgb, {"density": sigma[:, None], "interal_output": internal}
 
     def export_params(self) -> Dict:
         g = lambda p: p.detach().cpu().numpy()
@@ -198,13 +262,19 @@ def train_step(field: TrainableField, estimator, optimizer, rays_o: torch.Tensor
                                                        far_plane=far_plane, render_step_size=render_step_size,
                                                        stratified=True, cone_angle=cone_angle, alpha_thre=alpha_thre)
 
+    with_heads = field.use_feat_predict or field.use_weight_predict
+
     def rgb_sigma_fn(t_starts, t_ends, ray_indices):
         pos = rays_o[ray_indices] + rays_d[ray_indices] * ((t_starts + t_ends)[:, None] / 2.0)
-        return field(pos, ts[ray_indices], rays_d[ray_indices])
+        return field(pos, ts[ray_indices], rays_d[ray_indices], return_internal=with_heads)
 
-    colors, opacities, depths, _ = rendering_train(t_starts, t_ends, ray_indices, n_rays, rgb_sigma_fn,
-                                                    render_bkgd=render_bkgd)
+    colors, opacities, depths, extras = rendering_train(t_starts, t_ends, ray_indices, n_rays, rgb_sigma_fn,
+                                                         render_bkgd=render_bkgd)
     loss = torch.nn.functional.smooth_l1_loss(colors, target_rgb)
+    if "latent_losses" in extras:                          # train_real.py:400-409
+        loss = loss + extras["latent_losses"].mean()
+    if "weight_losses" in extras:
+        loss = loss + extras["weight_losses"].mean()
     optimizer.zero_grad(set_to_none=True)
     if grad_scaler is not None:                            # train_real.py:252,414-419 (GradScaler(2**10))
         grad_scaler.scale(loss).backward()

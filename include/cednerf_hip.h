@@ -287,6 +287,17 @@ int ced_scatter_pixels(int64_t n_rows, const float *src_rgb, int32_t stride_rgb,
                        int64_t n_pixels, float *rgb, float *opacity, float *depth, uint8_t *rgb8, int32_t width,
                        int32_t flip_w, void *stream);
 
+/* Bias-free dense layer over the sample stream, hand-written (csrc/linear.hip) in place of a library GEMM -- the
+ * forward and the input gradient of the tiny-cuda-nn Networks the reference trains through (cednerf/model.py:200-222,
+ * 280-344; loss.backward(), train_real.py:412-420):
+ *   transpose_w == 0:  y[s][o] = sum_i x[s][i] * w[o][i]     w [n_out, n_in]   (forward; relu != 0: y = max(y, 0))
+ *   transpose_w != 0:  y[s][o] = sum_i x[s][i] * w[i][o]     w [n_in, n_out]   (input gradient dz W of a layer W)
+ * then, when mask != NULL ([n, n_out]):  y[s][o] = mask[s][o] > 0 ? y[s][o] : 0  (the ReLU derivative of the layer
+ * below, fused).  x [n, n_in], y [n, n_out], widths 1..64, fp32 MFMA with fp32 accumulation.  w_rows / w_cols are
+ * checked against n_in / n_out.  The weight gradient of the same layer is ced_weight_grad. */
+int ced_linear(int64_t n, const float *x, int32_t n_in, const float *w, int32_t w_rows, int32_t w_cols,
+               int32_t transpose_w, int32_t n_out, int32_t relu, const float *mask, float *y, void *stream);
+
 int64_t ced_weight_grad_workspace_bytes(int64_t n, int32_t n_out, int32_t n_in);
 int ced_weight_grad(int64_t n, const float *x, int32_t n_in, const float *dy, int32_t n_out, float *dw,
                     void *workspace, int64_t workspace_bytes, void *stream);

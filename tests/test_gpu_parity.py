@@ -1260,7 +1260,8 @@ def test_bench_two_rank_rehearsal():
     env = dict(os.environ, CED_BENCH_BACKEND="gloo")
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
            "--master-port", str(free_port()), os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1",
-           "--width", "256", "--height", "256", "--no-cpu-baseline", "--also", "f16x2", "--min-seconds", "0.2"]
+           "--width", "256", "--height", "256", "--no-cpu-baseline", "--also", "f16x2", "--min-seconds", "0.2",
+           "--frames-per-call", "3"]
     out = subprocess.run(cmd, cwd=root, env=env, capture_output=True, text=True, timeout=600)
     assert out.returncode == 0, out.stderr[-2000:]
     lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
@@ -1285,7 +1286,8 @@ def test_bench_two_rank_rehearsal_strong_scaling():
     env = dict(os.environ, CED_BENCH_BACKEND="gloo")
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
            "--master-port", str(free_port()), os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1",
-           "--width", "256", "--height", "256", "--no-cpu-baseline", "--also", "", "--scaling", "strong", "--min-seconds", "0.2"]
+           "--width", "256", "--height", "256", "--no-cpu-baseline", "--also", "", "--scaling", "strong", "--min-seconds", "0.2",
+           "--frames-per-call", "3"]
     out = subprocess.run(cmd, cwd=root, env=env, capture_output=True, text=True, timeout=600)
     assert out.returncode == 0, out.stderr[-2000:]
     d = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][0])
@@ -1361,33 +1363,147 @@ def test_weight_grad_full_size_reproducible_and_rejects_bad_input(oracle):
     assert torch.allclose(got, odd[1:].sum(0, keepdim=True).expand(3, 19), atol=1e-5)
 
 
-def test_trainable_field_gradients_hip_weight_grad_vs_library(oracle):
-    """The parameter gradients of a training loss with dW through ced_weight_grad equal the all-library ones."""
+LINEAR_SHAPES = [(64, 64), (32, 64), (64, 6), (64, 3), (41, 64), (19, 64), (64, 16), (64, 32), (64, 1), (1, 1), (17, 33), (48, 64)]
+
+
+@pytest.mark.parametrize("n", [0, 1, 31, 33, 5000, 70001])
+def test_linear_kernel_matches_float64(oracle, n):
+    """ced_linear (csrc/linear.hip), the hand-written layer of the training path: forward with and without ReLU, the
+    input gradient (transposed weights) with the fused ReLU mask, every layer shape of the model and ragged ones,
+    against a float64 product."""
+    from ced_nerf_amd import ops
+    rng = np.random.default_rng(n + 3)
+    for n_in, n_out in LINEAR_SHAPES:
+        x = rng.normal(size=(n, n_in)).astype(np.float32)
+        w = rng.normal(size=(n_out, n_in)).astype(np.float32)
+        want = x.astype(np.float64) @ w.astype(np.float64).T
+        scale = max(1.0, np.abs(want).max()) if n else 1.0
+        for relu in (False, True):
+            got = N(ops.linear(T(x), T(w), relu=relu))
+            ref = np.maximum(want, 0) if relu else want
+            assert got.shape == (n, n_out)
+            if n:
+                assert np.abs(got - ref).max() <= 2e-6 * scale * max(n_in, 8), (n_in, n_out, relu)
+        # input gradient: dz [n, n_out] times W [n_out, n_in], masked by the layer input's sign
+        dz = rng.normal(size=(n, n_out)).astype(np.float32)
+        mask = rng.normal(size=(n, n_in)).astype(np.float32)
+        got = N(ops.linear(T(dz), T(w), transpose_w=True, mask=T(mask)))
+        ref = (dz.astype(np.float64) @ w.astype(np.float64)) * (mask > 0)
+        if n:
+            assert np.abs(got - ref).max() <= 2e-6 * max(1.0, np.abs(ref).max()) * max(n_out, 8), (n_in, n_out, "dx")
+    with pytest.raises(RuntimeError, match="widths must be 1..64"):
+        ops.linear(torch.zeros(4, 65, device=DEV), torch.zeros(3, 65, device=DEV))
+
+
+def test_mlp_autograd_node_matches_torch(oracle):
+    """`_MlpFn` (ced_linear + ced_weight_grad, one autograd node per MLP) against the same MLP in float64 torch."""
+    from ced_nerf_amd.train import _MlpFn
+    g = torch.Generator(device=DEV).manual_seed(2)
+    for dims in ((32, 64, 64, 64, 6), (41, 64, 16), (19, 64, 64, 3), (32, 64, 1)):
+        n = 4097
+        x = torch.randn(n, dims[0], device=DEV, generator=g, requires_grad=True)
+        ws = [torch.randn(dims[i + 1], dims[i], device=DEV, generator=g).mul_(0.3).requires_grad_() for i in range(len(dims) - 1)]
+        y = _MlpFn.apply(x, *ws)
+        up = torch.randn(y.shape, device=DEV, generator=g)
+        (y * up).sum().backward()
+        xd = x.detach().double().requires_grad_()
+        wd = [w.detach().double().requires_grad_() for w in ws]
+        h = xd
+        for i, w in enumerate(wd):
+            h = h @ w.t()
+            if i < len(wd) - 1:
+                h = torch.relu(h)
+        (h * up.double()).sum().backward()
+        assert (y.detach().double() - h.detach()).abs().max().item() <= 1e-4 * max(1.0, h.abs().max().item())
+        assert (x.grad.double() - xd.grad).abs().max().item() <= 1e-4 * max(1.0, xd.grad.abs().max().item()), dims
+        for a, b in zip(ws, wd):
+            assert (a.grad.double() - b.grad).abs().max().item() <= 2e-4 * max(1.0, b.grad.abs().max().item()), dims
+
+
+def test_rendering_train_extras_and_their_gradients(oracle):
+    """The training extras of cednerf/render.py:101-124 (latent / weight prediction losses reduced per ray) and the
+    differentiable (weights, trans) they use, against the same graph in plain float64 torch."""
+    from ced_nerf_amd.render import rendering_train
+    n_rays, seed = 300, 12
+    packed, t0, t1, sig, rgbs = _packed_problem(n_rays, seed)
+    ri = np.repeat(np.arange(n_rays), packed[:, 1]).astype(np.int64)
+    S = ri.shape[0]
+    rng = np.random.default_rng(seed)
+    lat = rng.uniform(0, 1, size=(S, 32)).astype(np.float32)
+    pw = rng.uniform(0, 1, size=(S, 1)).astype(np.float32)
+    sel = rng.uniform(size=S) < 0.9
+
+    def graph(dt, dev):
+        cv = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+        s_ = cv(sig).to(dt).requires_grad_(); c_ = cv(rgbs).to(dt).requires_grad_()
+        l_ = cv(lat).to(dt).requires_grad_(); p_ = cv(pw).to(dt).requires_grad_()
+        return s_, c_, l_, p_, cv
+
+    s_, c_, l_, p_, cv = graph(torch.float32, DEV)
+
+    def fn(ts, te, rix):
+        return c_, {"density": s_[:, None], "interal_output": {"selector": cv(sel), "latent_losses": l_, "weight_losses": p_}}
+    colors, op, dp, ex = rendering_train(cv(t0), cv(t1), cv(ri), n_rays, fn, render_bkgd=torch.ones(3, device=DEV))
+    loss = colors.sum() + ex["latent_losses"].mean() + ex["weight_losses"].mean() * 3.0
+    loss.backward()
+    # float64 reference
+    sd, cd, ld, pd_, cvd = graph(torch.float64, "cpu")
+    t0d, t1d, rid = cvd(t0).double(), cvd(t1).double(), cvd(ri)
+    sdl = sd * (t1d - t0d)
+    alpha = 1 - torch.exp(-sdl)
+    cs = torch.cumsum(sdl, 0)
+    starts = cvd(packed[:, 0]); first = cs[starts.clamp(max=S - 1)] - sdl[starts.clamp(max=S - 1)]
+    trans = torch.exp(-(cs - sdl - first[rid]))
+    w = trans * alpha
+    col = torch.zeros(n_rays, 3, dtype=torch.float64).index_add_(0, rid, w[:, None] * cd)
+    opd = torch.zeros(n_rays, 1, dtype=torch.float64).index_add_(0, rid, w[:, None])
+    col = col + 1.0 * (1 - opd)
+    latent = torch.zeros(n_rays, 32, dtype=torch.float64).index_add_(0, rid, w[:, None].detach() * ld)
+    wl = torch.nn.functional.huber_loss(pd_, trans[:, None], reduction="none") * cvd(sel)[:, None]
+    cnt = torch.bincount(rid, minlength=n_rays).double() + 1
+    wloss = torch.zeros(n_rays, 1, dtype=torch.float64).index_add_(0, rid, w[:, None] * wl) / cnt[:, None]
+    ref = col.sum() + latent.mean() + wloss.mean() * 3.0
+    ref.backward()
+    assert abs(loss.item() - ref.item()) <= 1e-4 * abs(ref.item())
+    assert (N(ex["latent_losses"]) - latent.detach().numpy()).__abs__().max() <= 1e-4
+    assert (N(ex["weight_losses"]) - wloss.detach().numpy()).__abs__().max() <= 1e-5
+    for nm, a, b in (("sigma", s_, sd), ("rgb", c_, cd), ("latent", l_, ld), ("p_weight", p_, pd_)):
+        err = (a.grad.cpu().double() - b.grad).abs().max().item()
+        assert err <= 2e-4 * max(1e-3, b.grad.abs().max().item()), (nm, err, b.grad.abs().max().item())
+
+
+def test_trainable_field_gradients_hip_vs_library(oracle):
+    """The parameter gradients of a training loss on the all-HIP MLPs (`_MlpFn`: ced_linear + ced_weight_grad) equal
+    the all-library ones (torch GEMMs), prediction heads included."""
     from ced_nerf_amd import synthetic as S
     from ced_nerf_amd.train import TrainableField
     p = S.init_field_params([-1.5, -1.5, -1.5, 1.5, 1.5, 1.5], 1e-3, 1024, 17, regime="init", seed=11, **dict(FIELD_CASES[0]))
     p["hash"]["table"] = (p["hash"]["table"] * 3000.0).astype(np.float32)
-    tf = TrainableField(p, DEV)
+    tf = TrainableField(p, DEV, use_feat_predict=True, use_weight_predict=True)
     rng = np.random.default_rng(6)
     n = 30000
     pos = T(rng.uniform(-1.4, 1.4, size=(n, 3)).astype(np.float32)); t = T(rng.uniform(0, 1, size=(n, 1)).astype(np.float32))
     d = T(rng.normal(size=(n, 3)).astype(np.float32)); wr = T(rng.normal(size=(n, 3)).astype(np.float32))
     grads = {}
     for mode in (True, False):
+        tf.hip_mlp = mode
         tf.hip_weight_grad = mode
         tf.zero_grad(set_to_none=True)
-        rgb, sig = tf(pos, t, d)
-        ((rgb * wr).sum() + sig.sum() * 0.1).backward()
+        rgb, res = tf(pos, t, d, return_internal=True)
+        io = res["interal_output"]
+        assert io["latent_losses"].shape == (n, 32) and io["weight_losses"].shape == (n, 1) and io["move"].shape == (n, 3)
+        ((rgb * wr).sum() + res["density"].sum() * 0.1 + io["latent_losses"].sum() * 1e3 + io["weight_losses"].sum()).backward()
         grads[mode] = [q.grad.clone() for q in tf.parameters()]
-    assert TrainableField.hip_weight_grad is True
+    assert TrainableField.hip_mlp is True and TrainableField.hip_weight_grad is True
+    assert any("mlp_feat_prediction" in nm for nm, _ in tf.named_parameters())
     for (name, _), a, b in zip(tf.named_parameters(), grads[True], grads[False]):
         assert a.abs().max().item() > 0, name
         assert (a - b).abs().max().item() <= 2e-4 * b.abs().max().item(), (name, (a - b).abs().max().item(), b.abs().max().item())
 
 
 def test_training_steps_reduce_the_loss(oracle):
-    """train.train_step end to end: HIP sampling, HIP hash forward/backward, library GEMMs, HIP compositing
-    forward/backward, Adam.  A student whose hash table was damaged relearns a teacher's renders."""
+    """train.train_step end to end: HIP sampling, HIP hash forward/backward, HIP MLPs (ced_linear / ced_weight_grad),
+    HIP compositing forward/backward, Adam.  A student whose hash table was damaged relearns a teacher's renders."""
     from ced_nerf_amd import synthetic as S
     from ced_nerf_amd.nerfacc_api import OccGridEstimator
     from ced_nerf_amd.train import TrainableField, train_step
