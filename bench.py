@@ -64,7 +64,8 @@ def parse():
                          "every frame's shard on its own render_image_test schedule (total work fixed)")
     ap.add_argument("--min-seconds", type=float, default=2.0,
                     help="after the contractual K-step window, further K-step windows are timed until this much time has "
-                         "been measured in all (at least 5, at most 24 windows): median / p10 / p90 in `windows`")
+                         "been measured in all (at least 5, at most 24 windows): median / p10 / p90 in `windows`; "
+                         "0: only the contractual window (profiling runs)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-single-frame", action="store_true",
                     help="skip the one-frame-alone latency measurement after the timed region (profiling runs: every "
@@ -274,7 +275,7 @@ def main():
     window_rates.append(samples_first / dt_first)
     timed = dt_first
     n_extra = 0
-    while (timed < args.min_seconds or n_extra < 4) and n_extra < 23:
+    while args.min_seconds > 0 and (timed < args.min_seconds or n_extra < 4) and n_extra < 23:
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize()

@@ -27,8 +27,9 @@ for k in sorted(set(fetch) | set(write)):
     res[k] = {"fetch_bytes_per_launch": fetch.get(k, {}).get("avg_kib", 0.0) * 1024,
               "write_bytes_per_launch": write.get(k, {}).get("avg_kib", 0.0) * 1024,
               "launches_profiled": fetch.get(k, {}).get("launches", 0)}
-res["_note"] = ("rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE in separate passes over `python bench.py --steps 3 "
-                "--warmup 1`; raw counter values x 1024 (KiB -> bytes); FETCH_SIZE is uncalibrated for 8-byte gathers on "
+res["_note"] = ("rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE in separate passes over `python bench.py --steps 5 --warmup 1 "
+                "--no-cpu-baseline --also= --no-single-frame --min-seconds 0` (the launches profiled are the warm-up step and the 5 "
+                "timed steps); raw counter values x 1024 (KiB -> bytes); FETCH_SIZE is uncalibrated for 8-byte gathers on "
                 "gfx950 (it under-counts wide streams 2x), WRITE_SIZE is exact for streaming stores")
 json.dump(res, open(out_path, "w"), indent=1)
 print(json.dumps(res, indent=1))
