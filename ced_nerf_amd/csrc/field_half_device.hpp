@@ -47,20 +47,21 @@ template <bool SPLIT> __device__ __forceinline__ void to_half8(const float (&v)[
 
 typedef _Float16 h4 __attribute__((ext_vector_type(4)));
 
-// One K = 32 product block of D^T = W * X^T.  gfx950's v_mfma_f32_16x16x32_f16 does it in one instruction,
-// but under ROCm 7.2 kernels built on it were NOT reproducible on MI355X: with two or three waves per SIMD about
-// 0.2 % of the 16-sample tiles came out wrong, different ones on every run, always the tile whose MFMA is the last
-// reader of the group's A operand.  It is not a software-visible hazard: scheduler fences and s_nop pads around
-// the MFMA groups and pinning the operand registers moved the failure between the f16x2 and f16 variants but
-// never removed it from both, and with EVERY such MFMA fenced, padded before and after and its operands pinned
-// the kernels were still irreproducible -- more so the longer the pads, i.e. the more other waves' MFMAs got in
-// between (tools/debug_half.py is the reproducer; define CED_HALF_MFMA_K32 to build that form).  The same block issued as
-// two v_mfma_f32_16x16x16_f16 over the low / high four halves of each lane's operands -- the same index pairing,
-// hence the same sum, no data movement -- is reproducible over repeated 15 M-sample launches in both variants, and
-// is what ships (f16x2: 3.6 instead of 4.2 Gsamples/s; f16: 5.1 either way).
+// One K = 32 product block of D^T = W * X^T: gfx950's v_mfma_f32_16x16x32_f16.
+//
+// Hazard this file depends on (found in round 2): while a wave of a SIMD executes that MFMA, a
+// packed-fp32 VALU instruction of ANOTHER wave of the SIMD whose op_sel takes the HIGH half of src1 for the low
+// result lane (v_pk_mul_f32 / v_pk_add_f32 ... op_sel:[0,1], v_pk_fma_f32 ... op_sel:[0,1,0]) reads that operand
+// as zero, about once in 1e4 executions (tools/probes/pk_opsel_mfma.hip isolates it: never without the MFMA,
+// never beside v_mfma_f32_16x16x16_f16, never for un-swizzled, op_sel_hi or src0/src2 swizzles).  hipcc's SLP
+// vectoriser emits exactly that form (it did in the hash-coordinate arithmetic of round 1's kernels, which is why
+// they were irreproducible on this MFMA and fine on the 16x16x16 pair), so the library is built with
+// -fno-slp-vectorize and tools/isa_lint.py (tests/test_cabi_cpu.py) rejects any kernel that contains the form.
+// -DCED_HALF_MFMA_K16 rebuilds the block as two v_mfma_f32_16x16x16_f16 over the low / high four halves of each
+// lane's operands (f16x2: 3.8 instead of 4.2 Gsamples/s; f16: 5.2 either way).
 __device__ __forceinline__ f4 mfma_k32(const h8 &a, const h8 &b, f4 c)
 {
-#ifdef CED_HALF_MFMA_K32
+#ifndef CED_HALF_MFMA_K16
     return __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, c, 0, 0, 0);
 #else
     const h4 a0 = { a[0], a[1], a[2], a[3] }, a1 = { a[4], a[5], a[6], a[7] };
@@ -92,9 +93,9 @@ __device__ __forceinline__ void mlp_layer_h(const _Float16 *__restrict__ whi, co
             }
 #pragma unroll
             for (int j = 0; j < NT; ++j) acc[j] = mfma_k32(ah, Bh[j][ks], acc[j]);
-            // Group fence: the MFMAs of a group issue back to back and the group's operands stay allocated
-            // until the pad below has passed (a left-over of the hunt described at mfma_k32; it costs nothing
-            // measurable and keeps the conversions of the next operands out of the MFMA stream).
+            // Group fence: the MFMAs of a group issue back to back; it keeps the conversions of the next operands
+            // out of the MFMA stream (the pad and the operand pins are left-overs of round 1's hunt for the hazard
+            // described at mfma_k32 and cost nothing measurable).
             __builtin_amdgcn_sched_barrier(0);
             asm volatile("s_nop %0" ::"n"(CED_HALF_MFMA_GUARD));
             asm volatile("" ::"v"(ah));

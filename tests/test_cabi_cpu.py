@@ -304,3 +304,29 @@ def test_oracle_occ_grid_update_known_answers(oracle):
     assert np.allclose(seen["x"], [[0.125, 0.125, 0.125], [0.125, 0.375, 0.875], [0.875, 0.875, 0.875]])
     assert out[0] == np.float32(0.2) and out[7] == np.float32(0.45) and out[63] == 0.0 and out[5] == -1.0
     assert binaries.sum() == 2 and binaries[0] and binaries[7]        # mean of visible = 0.65/63 ~ 0.0103 -> thre 0.01
+
+
+def test_built_library_has_no_src1_high_op_sel_packed_fp32():
+    """gfx950 hazard (tools/probes/pk_opsel_mfma.hip): v_pk_{mul,add,fma}_f32 with op_sel taking the high
+    half of src1 for the low lane reads zero beside another wave's v_mfma_f32_16x16x32_f16.  The library is built with
+    -fno-slp-vectorize so that hipcc never forms it; this checks the code objects actually built."""
+    import importlib.util
+    import shutil
+    from ced_nerf_amd import _lib
+    spec = importlib.util.spec_from_file_location(
+        "isa_lint", os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools", "isa_lint.py"))
+    lint = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(lint)
+    # the pattern itself: the forms the probe shows to fail, and the ones it shows to be safe
+    for bad in ("v_pk_mul_f32 v[0:1], v[2:3], v[4:5] op_sel:[0,1]", "v_pk_add_f32 v[0:1], v[2:3], v[4:5] op_sel:[0,1] op_sel_hi:[1,0]",
+                "v_pk_fma_f32 v[0:1], v[2:3], v[4:5], v[6:7] op_sel:[0,1,0]"):
+        assert lint.FORBIDDEN.search(bad), bad
+    for ok in ("v_pk_mul_f32 v[0:1], v[2:3], v[4:5] op_sel_hi:[0,1]", "v_pk_mul_f32 v[0:1], v[2:3], v[4:5] op_sel:[1,0]",
+               "v_pk_fma_f32 v[0:1], v[2:3], v[4:5], v[6:7] op_sel:[0,0,1]", "v_pk_mov_b32 v[0:1], v[2:3], v[4:5] op_sel:[1,1]"):
+        assert not lint.FORBIDDEN.search(ok), ok
+    assert "-fno-slp-vectorize" in _lib.HIPCC_FLAGS
+    if not (os.path.exists(lint.OBJDUMP) or shutil.which(lint.OBJDUMP)):
+        pytest.skip("llvm-objdump not found")
+    n, bad = lint.scan(_lib.build())
+    assert n > 100, f"only {n} kernels found in the library"
+    assert not bad, f"kernels with a src1-high op_sel packed-fp32 instruction: {sorted(bad)}"

@@ -10,7 +10,7 @@ OBJ=$R/build/obj
 mkdir -p $OBJ/var_$NAME
 python3 -c "import sys; sys.path.insert(0,'$R'); from ced_nerf_amd import _lib; _lib.build()"
 for f in ${SRCS:-frame accel march}; do
-  hipcc --offload-arch=gfx950 -O3 -ffp-contract=off -fPIC -std=c++17 "$@" -c $R/ced_nerf_amd/csrc/$f.hip -o $OBJ/var_$NAME/$f.hip.o &
+  hipcc --offload-arch=gfx950 -O3 -ffp-contract=off -fno-slp-vectorize -fPIC -std=c++17 "$@" -c $R/ced_nerf_amd/csrc/$f.hip -o $OBJ/var_$NAME/$f.hip.o &
 done
 wait
 OBJS=""

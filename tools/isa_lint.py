@@ -1,0 +1,60 @@
+#!/usr/bin/env python3
+"""ISA lint of the built library: no kernel may contain a packed-fp32 VALU instruction whose op_sel takes the HIGH half
+of src1 for the low result lane (v_pk_mul_f32 / v_pk_add_f32 ... op_sel:[x,1], v_pk_fma_f32 ... op_sel:[x,1,x]).
+
+On gfx950 that form reads the swizzled operand as zero while another wave of the same SIMD executes
+v_mfma_f32_16x16x32_f16 (tools/probes/pk_opsel_mfma.hip) -- and the half-precision field kernels run that
+MFMA three waves to a SIMD, beside the other kernels of frames in flight.  hipcc's SLP vectoriser is what emits the form,
+hence -fno-slp-vectorize in ced_nerf_amd/_lib.py; this lint is the check that an edit or a flag change has not brought
+it back.  Usage: tools/isa_lint.py [library.so]   (exit status 1 and a list of kernels when the form is present)
+"""
+import os
+import re
+import subprocess
+import sys
+import tempfile
+
+OBJDUMP = os.environ.get("LLVM_OBJDUMP", "/opt/rocm/lib/llvm/bin/llvm-objdump")
+FORBIDDEN = re.compile(r"\b(v_pk_(?:mul|add|fma|min|max)_f32)\b[^\n]*?\bop_sel:\[[01],1")
+
+
+def code_objects(path):
+    """the AMDGPU ELF images inside a HIP fat binary (.so)"""
+    blob = open(path, "rb").read()
+    starts = [m.start() for m in re.finditer(b"\x7fELF\x02\x01\x01\x40", blob)]
+    for k, i in enumerate(starts):
+        yield blob[i:starts[k + 1] if k + 1 < len(starts) else len(blob)]
+
+
+def scan(path):
+    """-> (number of kernels scanned, {kernel: [offending instruction lines]})"""
+    bad, n_kernels = {}, 0
+    for image in code_objects(path):
+        with tempfile.NamedTemporaryFile(suffix=".co") as f:
+            f.write(image)
+            f.flush()
+            text = subprocess.run([OBJDUMP, "-d", f.name], capture_output=True, text=True, check=True).stdout
+        kernel = None
+        for line in text.splitlines():
+            m = re.match(r"^[0-9a-f]+ <(\S+)>:", line)
+            if m:
+                kernel = m.group(1)
+                n_kernels += 1
+                continue
+            if FORBIDDEN.search(line):
+                bad.setdefault(kernel, []).append(line.split("//")[0].strip())
+    return n_kernels, bad
+
+
+def main():
+    here = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    path = sys.argv[1] if len(sys.argv) > 1 else os.path.join(here, "ced_nerf_amd", "libcednerf_hip.so")
+    n, bad = scan(path)
+    print(f"{path}: {n} kernels scanned, {len(bad)} with a src1-high op_sel packed-fp32 instruction")
+    for k, lines in bad.items():
+        print(f"  {k}: {len(lines)}   e.g. {lines[0]}")
+    return 1 if bad else 0
+
+
+if __name__ == "__main__":
+    sys.exit(main())
