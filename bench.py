@@ -381,6 +381,36 @@ def main():
         single_ms = float(np.median(single_times))
         single_stats = {"median": single_ms, "p10": float(np.quantile(single_times, 0.1)),
                         "p90": float(np.quantile(single_times, 0.9)), "frames": len(single_times)}
+    # secondary entry (a2): cednerf.utils.render_image (eval) on frame 0 -- `sampling` with its visibility filter, then
+    # `rendering`; the native pass evaluates the field once per sample and stops rays at the filter's threshold
+    render_image_entry = None
+    if not args.no_single_frame:
+        from ced_nerf_amd.utils import Rays, render_image
+        rays0 = Rays(T(frames[0]["origins"]), T(frames[0]["viewdirs"]))
+        ri_kw = dict(timestamps=ts, **rk)
+        out = render_image(field, est, rays0, **ri_kw)
+        torch.cuda.synchronize()
+        ri_times = []
+        for _ in range(10):
+            torch.cuda.synchronize()
+            t1 = time.perf_counter()
+            out = render_image(field, est, rays0, **ri_kw)
+            torch.cuda.synchronize()
+            ri_times.append((time.perf_counter() - t1) * 1e3)
+        staged = []
+        for _ in range(3):
+            torch.cuda.synchronize()
+            t1 = time.perf_counter()
+            ref = render_image(field, est, rays0, native=False, **ri_kw)
+            torch.cuda.synchronize()
+            staged.append((time.perf_counter() - t1) * 1e3)
+        render_image_entry = {
+            "ms_per_frame": float(np.median(ri_times)), "p10": float(np.quantile(ri_times, 0.1)),
+            "p90": float(np.quantile(ri_times, 0.9)), "frames": len(ri_times), "kept_samples": int(out[3]),
+            "staged_ms_per_frame": float(np.median(staged)),
+            "equal_to_staged": bool(out[3] == ref[3] and all(torch.equal(out[i], ref[i]) for i in range(3))),
+            "note": "cednerf.utils.render_image (eval, utils.py:46-150) on frame 0, one GPU; staged = sampling over every "
+                    "marched sample with sigma_fn, then rendering (the reference's composition on the same kernels)"}
     fp16 = sc["params"]["hash"]["table"].dtype == np.float16
     line = {
         "metric": "samples_per_sec (render_image_test, 800x800 D-NeRF lego-shaped synthetic)",
@@ -392,6 +422,7 @@ def main():
         "rays_per_sec": n_rays_step * args.steps / dt,
         "ms_per_frame": 1e3 * dt / args.steps / (lanes * per_call),
         "single_frame_latency_ms": single_ms, "single_frame_latency_stats_ms": single_stats,
+        "render_image": render_image_entry,
         "windows": {"n": len(window_rates), "steps_each": args.steps, "seconds": timed, "unit": "samples/s",
                     "median": float(np.median(window_rates)), "p10": float(np.quantile(window_rates, 0.1)),
                     "p90": float(np.quantile(window_rates, 0.9)), "first": window_rates[0],

@@ -66,6 +66,14 @@ __global__ __launch_bounds__(THREADS) void field_half_kernel(FieldArgs A)
         const int64_t nd = *A.n_dev;
         n_eff = nd < n_eff ? nd : n_eff;
     }
+    if (A.base_dev) {               // the call's window of persistent sample arrays (render_image: frame.hip)
+        const int64_t b = *A.base_dev;
+        if (A.ray_idx32) A.ray_idx32 += b;
+        if (A.ray_idx) A.ray_idx += b;
+        A.t0 += b; A.t1 += b;
+        A.sigma += b;
+        if (A.rgb) A.rgb += 3 * b;
+    }
     const int64_t n_tiles = (n_eff + TILE - 1) / TILE;
     // a workgroup without a tile leaves before staging anything (see field.hip)
     if ((A.spread_tiles ? (int64_t)blockIdx.x * 4 : (int64_t)blockIdx.x * WAVES) >= n_tiles) return;

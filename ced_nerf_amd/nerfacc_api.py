@@ -322,10 +322,10 @@ class OccGridEstimator(torch.nn.Module):
                 self.occs[lvl * self.cells_per_lvl + idx] = torch.where(valid, 0.0, -1.0)
 
     @torch.no_grad()
-    def sampling(self, rays_o, rays_d, sigma_fn: Optional[Callable] = None, alpha_fn: Optional[Callable] = None,
-                 near_plane: float = 0.0, far_plane: float = 1e10, t_min=None, t_max=None,
-                 render_step_size: float = 1e-3, early_stop_eps: float = 1e-4, alpha_thre: float = 0.0,
-                 stratified: bool = False, cone_angle: float = 0.0) -> Tuple[torch.Tensor, torch.Tensor, torch.Tensor]:
+    def march(self, rays_o, rays_d, near_plane: float = 0.0, far_plane: float = 1e10, t_min=None, t_max=None,
+              render_step_size: float = 1e-3, stratified: bool = False, cone_angle: float = 0.0):
+        """The marching half of `sampling`: every sample inside occupied cells, all rays to the far plane.
+        Returns (t_starts, t_ends, ray_indices, packed_info)."""
         rays_o = rays_o.contiguous(); rays_d = rays_d.contiguous()
         near_planes = torch.full_like(rays_o[..., 0], fill_value=near_plane)
         far_planes = torch.full_like(rays_o[..., 0], fill_value=far_plane)
@@ -338,6 +338,14 @@ class OccGridEstimator(torch.nn.Module):
         t_starts, t_ends, ray_indices, packed_info, _ = march_packed(
             rays_o, rays_d, self.binaries, self.aabbs, near_planes.contiguous(), far_planes.contiguous(),
             render_step_size, cone_angle)
+        return t_starts, t_ends, ray_indices, packed_info
+
+    def sampling(self, rays_o, rays_d, sigma_fn: Optional[Callable] = None, alpha_fn: Optional[Callable] = None,
+                 near_plane: float = 0.0, far_plane: float = 1e10, t_min=None, t_max=None,
+                 render_step_size: float = 1e-3, early_stop_eps: float = 1e-4, alpha_thre: float = 0.0,
+                 stratified: bool = False, cone_angle: float = 0.0) -> Tuple[torch.Tensor, torch.Tensor, torch.Tensor]:
+        t_starts, t_ends, ray_indices, packed_info = self.march(rays_o, rays_d, near_plane, far_plane, t_min, t_max,
+                                                                render_step_size, stratified, cone_angle)
         if (alpha_thre > 0.0 or early_stop_eps > 0.0) and (sigma_fn is not None or alpha_fn is not None):
             alpha_thre = min(alpha_thre, self.occs.mean().item())
             if alpha_fn is not None:

@@ -532,6 +532,64 @@ def render_image_test_native(desc: _lib.FieldDesc, rays_o, rays_d, binaries, aab
     return rgb, opacity, depth, int(total.value)
 
 
+_image_ws: Dict[tuple, tuple] = {}
+
+
+def render_image_eval_native(desc: _lib.FieldDesc, rays_o, rays_d, packed_info, t_starts, t_ends, early_stop_eps,
+                             alpha_thre, timestamps, t_per_ray, bkgd, chunk_rays: int = 0, max_workgroups: int = 0):
+    """ced_render_image + ced_render_image_gather: `sampling` (visibility filter) and `rendering` of cednerf/utils.py:115-133
+    from one field evaluation per sample.  (packed_info, t_starts, t_ends): the one-shot march of all rays.
+    Returns (rgb [n,3], opacity [n,1], depth [n,1], extras, ray_offsets [n+1] int64, stats) where extras holds the
+    kept samples' ray_indices (relative to chunks of `chunk_rays` rays when > 0), t_starts, t_ends, sigmas, rgbs,
+    weights, trans, alphas in the reference's order, and stats = (samples evaluated, iterations)."""
+    _chk(rays_o, torch.float32, "rays_o"); _chk(rays_d, torch.float32, "rays_d")
+    _chk(packed_info, torch.int64, "packed_info"); _chk(t_starts, torch.float32, "t_starts")
+    _chk(t_ends, torch.float32, "t_ends"); _chk(timestamps, torch.float32, "timestamps")
+    _chk(bkgd, torch.float32, "render_bkgd", allow_none=True)
+    assert rays_o.ndim == 2 and rays_o.shape[1] == 3 and rays_o.shape == rays_d.shape
+    n = rays_o.shape[0]
+    n_all = t_starts.shape[0]
+    assert packed_info.shape == (n, 2) and t_ends.shape == (n_all,)
+    if t_per_ray:
+        assert timestamps.numel() == n, "per-ray timestamps must have one entry per ray"
+    dev = rays_o.device
+    L = _lib.lib()
+    need = int(L.ced_render_image_workspace_bytes(n, n_all))
+    if need < 0:
+        raise ValueError("render_image: unsupported sizes")
+    key = (dev.index, torch.cuda.current_stream().cuda_stream)
+    with _frame_ws_lock:
+        ws = _image_ws.get(key)
+        if ws is None or ws[0].numel() < need:
+            ws = (torch.empty((max(need, 1),), device=dev, dtype=torch.uint8),
+                  ws[1] if ws is not None else torch.zeros((512,), dtype=torch.int64).pin_memory())
+            _image_ws[key] = ws
+    rgb = torch.empty((n, 3), device=dev, dtype=torch.float32)
+    opacity = torch.empty((n, 1), device=dev, dtype=torch.float32)
+    depth = torch.empty((n, 1), device=dev, dtype=torch.float32)
+    kept = torch.empty((n,), device=dev, dtype=torch.int32)
+    stats = (C.c_int64 * 3)()
+    rc = L.ced_render_image(C.byref(_with_workgroups(desc, max_workgroups)), n, _p(rays_o), _p(rays_d), n_all,
+                            _p(packed_info), _p(t_starts), _p(t_ends), float(early_stop_eps), float(alpha_thre),
+                            _p(timestamps), int(bool(t_per_ray)), _p(bkgd), _p(rgb), _p(opacity), _p(depth), _p(kept),
+                            _p(ws[0]), ws[0].numel(), C.c_void_p(ws[1].data_ptr()), stats, None, _stream())
+    _lib.check(rc, "render_image")
+    processed = int(stats[0])
+    offsets = torch.zeros((n + 1,), device=dev, dtype=torch.int64)
+    torch.cumsum(kept, 0, out=offsets[1:])
+    total = int(offsets[-1].item()) if n > 0 else 0
+    f = lambda *shape: torch.empty(shape, device=dev, dtype=torch.float32)
+    extras = {"ray_indices": torch.empty((total,), device=dev, dtype=torch.int64), "t_starts": f(total), "t_ends": f(total),
+              "sigmas": f(total), "rgbs": f(total, 3), "weights": f(total), "trans": f(total), "alphas": f(total)}
+    if total > 0:               # (an alpha threshold can drop every sample of a faint scene)
+        rc = L.ced_render_image_gather(n, n_all, processed, _p(ws[0]), ws[0].numel(), _p(offsets), int(chunk_rays),
+                                       _p(extras["ray_indices"]), _p(extras["t_starts"]), _p(extras["t_ends"]),
+                                       _p(extras["sigmas"]), _p(extras["rgbs"]), _p(extras["weights"]), _p(extras["trans"]),
+                                       _p(extras["alphas"]), _stream())
+        _lib.check(rc, "render_image_gather")
+    return rgb, opacity, depth, extras, offsets, (processed, int(stats[1]))
+
+
 def render_frames_test_native(desc: _lib.FieldDesc, n_frames: int, rays_o, rays_d, binaries, aabbs, near_plane, far_plane,
                               render_step_size, cone_angle, early_stop_eps, max_samples, frame_times, bkgd,
                               tracer: Optional[FrameTracer] = None, field_stream: Optional[torch.cuda.Stream] = None,

@@ -77,13 +77,22 @@ def render_image(
     alpha_thre: float = 0.0,
     test_chunk_size: int = 8192,
     timestamps: Optional[torch.Tensor] = None,
+    native: Optional[bool] = None,
 ):
     """Render the pixels of an image (cednerf/utils.py:46-150).
-    Returns (colors, opacities, depths, n_rendering_samples, extras[list per chunk])."""
+    Returns (colors, opacities, depths, n_rendering_samples, extras[list per chunk]).
+    In eval mode with the HIP field the pass runs on ced_render_image: the visibility filter of `sampling` and
+    `rendering` from ONE field evaluation per sample, rays stopped where their transmittance falls below the filter's
+    threshold -- the same arrays bit for bit (tests/test_gpu_parity.py).  native=False forces the staged composition
+    (sampling with sigma_fn, then rendering) that training mode always uses."""
     if timestamps is None:
         raise NotImplementedError("DNGPradianceField needs timestamps (dnerf path of cednerf/utils.py:78-86)")
     rays, rays_shape, num_rays = _flatten_rays(rays)
     results, extra_info = [], []
+    if native is None:
+        native = (not radiance_field.training) and hasattr(radiance_field, "_descriptor") and rays.origins.is_cuda
+    if native:
+        assert not radiance_field.training, "the native render_image pass is the eval path"
     # The reference renders 8192 rays per pass in eval mode to bound memory (cednerf/utils.py:59,108-112).
     # Rays are independent, so here a pass covers up to `_EVAL_PASS_RAYS` rays (HBM is not the
     # constraint on MI355X) and its outputs are then cut into the reference's `test_chunk_size`
@@ -96,6 +105,33 @@ def render_image(
     for i in range(0, num_rays, pass_rays):
         chunk_rays = namedtuple_map(lambda r: r[i:i + pass_rays].contiguous().float(), rays)
         ts = timestamps[i:i + pass_rays] if training else timestamps
+        n_pass = chunk_rays.origins.shape[0]
+        if native:
+            t_all0, t_all1, _, packed_all = estimator.march(
+                chunk_rays.origins, chunk_rays.viewdirs, near_plane=near_plane, far_plane=far_plane,
+                render_step_size=render_step_size, stratified=False, cone_angle=cone_angle)
+            thre = float(alpha_thre)
+            if thre > 0.0:                                      # nerfacc: alpha_thre = min(alpha_thre, occs.mean())
+                thre = min(thre, estimator.occs.mean().item())
+            bk = None if render_bkgd is None else render_bkgd.to(chunk_rays.origins.device, torch.float32).reshape(-1).contiguous()
+            chunked = n_pass > test_chunk_size
+            rgb, opacity, depth, ex, offsets, _ = ops.render_image_eval_native(
+                radiance_field._descriptor(), chunk_rays.origins, chunk_rays.viewdirs, packed_all, t_all0, t_all1,
+                1e-4, thre, ts.reshape(-1).float().contiguous(), False, bk,
+                chunk_rays=test_chunk_size if chunked else 0)
+            extras = {k: ex[k] for k in ("weights", "alphas", "trans", "sigmas", "rgbs", "ray_indices", "t_starts", "t_ends")}
+            # a pass's pixels stay whole (cutting them into chunks only to concatenate them again would be ~250 slice
+            # calls); the per-chunk `extras` are views cut by one split() per array
+            results.append([rgb, opacity, depth, int(extras["t_starts"].shape[0])])
+            if not chunked:
+                extra_info.append(extras)
+                continue
+            starts = list(range(0, n_pass, test_chunk_size)) + [n_pass]
+            bounds = offsets[torch.tensor(starts, device=offsets.device)].tolist()
+            sizes = [bounds[c + 1] - bounds[c] for c in range(len(starts) - 1)]
+            cut = {k: v.split(sizes) for k, v in extras.items()}
+            extra_info.extend([{k: cut[k][c] for k in cut} for c in range(len(sizes))])
+            continue
 
         def sigma_fn(t_starts, t_ends, ray_indices):
             return radiance_field.query_rays(chunk_rays.origins, chunk_rays.viewdirs, ray_indices, t_starts, t_ends,
@@ -108,7 +144,6 @@ def render_image(
         ray_indices, t_starts, t_ends = estimator.sampling(
             chunk_rays.origins, chunk_rays.viewdirs, sigma_fn=sigma_fn, near_plane=near_plane, far_plane=far_plane,
             render_step_size=render_step_size, stratified=training, cone_angle=cone_angle, alpha_thre=alpha_thre)
-        n_pass = chunk_rays.origins.shape[0]
         rgb, opacity, depth, extras = rendering(t_starts, t_ends, ray_indices, n_rays=n_pass,
                                                 rgb_sigma_fn=rgb_sigma_fn, render_bkgd=render_bkgd)
         extras["ray_indices"] = ray_indices

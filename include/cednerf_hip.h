@@ -427,6 +427,34 @@ int ced_render_frames_test(const ced_field_desc *field, int32_t n_frames, int64_
                            void *workspace, int64_t workspace_bytes, int64_t *host_stats,
                            int64_t *total_samples_out, ced_frame_trace *trace, void *field_stream, void *stream);
 
+/* ---- render_image in eval mode: cednerf/utils.py:46-150 (`estimator.sampling` with sigma_fn, then `rendering`) ----
+ * The reference evaluates the density of EVERY marched sample (nerfacc OccGridEstimator.sampling ->
+ * render_visibility_from_density, call site cednerf/utils.py:115-125) and then the whole field again on the survivors
+ * (cednerf/render.py:81-87).  This entry returns the same arrays, bit for bit, from ONE field evaluation per sample:
+ * each ray's samples are walked front to back in chunks and a ray stops at the first sample whose transmittance so
+ * far is below early_stop_eps (the kept samples of a ray are a prefix of its march, so the rest can never be kept).
+ * Inputs: the one-shot march of all rays -- packed_info [n_rays, 2] (first sample, count), t_starts / t_ends [n_all],
+ * as ced_traverse_grids produces them (samples sorted by ray).  timestamps as in ced_field_forward_rays.
+ * Outputs per ray: rgb [n_rays, 3], opacity, depth (finalised as cednerf/render.py:158-176: background blend, depth /
+ * max(opacity, eps)), kept [n_rays] = kept samples of the ray.  stats_out (host int64 [3]): [0] samples evaluated
+ * (entries of the workspace's sample arrays), [1] iterations.  host_stats: PINNED host memory, >= 64 bytes (the
+ * iteration schedule is computed on the device and published there, as in ced_render_image_test).  The call returns
+ * after one stream synchronisation (the sample total is needed to size the outputs of the gather).
+ * ced_render_image_gather then writes the per-sample `extras` of the kept samples in the reference's order (by ray,
+ * then along the ray): ray_offsets [n_rays] = exclusive prefix sum of `kept` (int64), outputs of sum(kept) entries;
+ * chunk_rays > 0 makes ray_indices relative to the ray's chunk of that many rays (the reference's chunked eval loop,
+ * cednerf/utils.py:108-133), 0 keeps them absolute. */
+int64_t ced_render_image_workspace_bytes(int64_t n_rays, int64_t n_all);
+int ced_render_image(const ced_field_desc *field, int64_t n_rays, const float *rays_o, const float *rays_d,
+                     int64_t n_all, const int64_t *packed_info, const float *t_starts, const float *t_ends,
+                     float early_stop_eps, float alpha_thre, const float *timestamps, int32_t t_per_ray,
+                     const float *bkgd, float *rgb, float *opacity, float *depth, int32_t *kept, void *workspace,
+                     int64_t workspace_bytes, int64_t *host_stats, int64_t *stats_out, void *field_stream, void *stream);
+int ced_render_image_gather(int64_t n_rays, int64_t n_all, int64_t processed, const void *workspace,
+                            int64_t workspace_bytes, const int64_t *ray_offsets, int64_t chunk_rays,
+                            int64_t *ray_indices, float *t_starts, float *t_ends, float *sigmas, float *rgbs,
+                            float *weights, float *trans, float *alphas, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -660,12 +660,91 @@ def test_render_image_parity(oracle, name, regime, wh):
         assert w[3] < w[5]          # the visibility filter removed something
 
 
+@pytest.mark.parametrize("name,wh,chunk,alpha_thre", [("dnerf", (80, 60), 1000, 0.0), ("dnerf", (80, 60), 8192, 0.0),
+                                                       ("hypernerf", (48, 64), 700, 0.0), ("dnerf", (64, 48), 1000, 0.02)])
+def test_render_image_native_pass_matches_staged_composition(oracle, name, wh, chunk, alpha_thre):
+    """The eval pass of render_image on ced_render_image (one field evaluation per sample, rays stopped at the
+    visibility threshold) against the staged composition it replaces (sampling with sigma_fn over every marched sample,
+    then rendering): every returned array bit for bit, chunked and unchunked, with and without an alpha threshold."""
+    from ced_nerf_amd.utils import render_image
+    sc = _scene(name, wh[0], wh[1], "trained", log2_hashmap_size=17)
+    of, oest, f, est, rays, rk = _setup(oracle, sc)
+    rk = dict(rk); rk["alpha_thre"] = alpha_thre
+    if alpha_thre > 0.0:
+        est.occs = torch.full_like(est.occs, 1.0)               # nerfacc clamps alpha_thre to occs.mean()
+    ts = T(sc["timestamps"])
+    a = render_image(f, est, rays, timestamps=ts, test_chunk_size=chunk, native=True, **rk)
+    b = render_image(f, est, rays, timestamps=ts, test_chunk_size=chunk, native=False, **rk)
+    assert a[3] == b[3] and len(a[4]) == len(b[4]) and a[3] > 0
+    for ae, be in zip(a[4], b[4]):
+        assert set(ae) == set(be)
+        for k in be:
+            assert ae[k].dtype == be[k].dtype and ae[k].shape == be[k].shape, k
+            assert torch.equal(ae[k], be[k]), f"extras[{k}]"
+    for i, nm in enumerate(("colors", "opacities", "depths")):
+        assert a[i].shape == b[i].shape and torch.equal(a[i], b[i]), nm
+    if alpha_thre > 0.0:
+        al = torch.cat([e["alphas"] for e in a[4]])
+        assert bool((al >= alpha_thre).all())
+
+
+def test_render_image_native_pass_empty_and_ragged(oracle):
+    """Rays that miss the grid (no samples), a pass smaller than a chunk, and zero rays."""
+    from ced_nerf_amd.utils import Rays, render_image
+    sc = _scene("dnerf", 40, 30, "trained", log2_hashmap_size=17)
+    of, oest, f, est, rays, rk = _setup(oracle, sc)
+    ts = T(sc["timestamps"])
+    o = rays.origins.reshape(-1, 3).clone(); d = rays.viewdirs.reshape(-1, 3).clone()
+    d[::3] = -d[::3]                                               # a third of the rays look away from the box
+    r2 = Rays(o[:777].contiguous(), d[:777].contiguous())
+    a = render_image(f, est, r2, timestamps=ts, native=True, **rk)
+    b = render_image(f, est, r2, timestamps=ts, native=False, **rk)
+    assert a[3] == b[3] and len(a[4]) == len(b[4]) == 1
+    for k in b[4][0]:
+        assert torch.equal(a[4][0][k], b[4][0][k]), k
+    for i in range(3):
+        assert torch.equal(a[i], b[i])
+    away = Rays(o[::3][:50].contiguous(), d[::3][:50].contiguous())
+    e = render_image(f, est, away, timestamps=ts, native=True, **rk)
+    g = render_image(f, est, away, timestamps=ts, native=False, **rk)
+    assert e[3] == g[3] and all(torch.equal(e[i], g[i]) for i in range(3))
+
+
 # ---- full-size checks (BASELINE.json config 2: 800x800, T = 2^21) ---------------------------------
 @pytest.fixture(scope="module")
 def full_frame(oracle):
     sc = _scene("dnerf", 800, 800, "trained")
     of, oest, f, est, rays, rk = _setup(oracle, sc)
     return sc, of, oest, f, est, rays, rk
+
+
+def test_full_size_render_image_native_pass(oracle, full_frame):
+    """800x800 (BASELINE config 2): render_image through ced_render_image equals the staged composition in every pixel
+    and every per-sample array, and evaluates the field on far fewer samples than the march holds."""
+    from ced_nerf_amd import ops
+    from ced_nerf_amd.utils import render_image
+    sc, of, oest, f, est, rays, rk = full_frame
+    ts = T(sc["timestamps"])
+    a = render_image(f, est, rays, timestamps=ts, native=True, **rk)
+    b = render_image(f, est, rays, timestamps=ts, native=False, **rk)
+    assert a[3] == b[3] and len(a[4]) == len(b[4]) == (640000 + 8191) // 8192
+    for i in range(3):
+        assert torch.equal(a[i], b[i])
+    for c in (0, 17, len(a[4]) // 2, len(a[4]) - 1):
+        for k in b[4][c]:
+            assert torch.equal(a[4][c][k], b[4][c][k]), (c, k)
+    cat = lambda lst, k: torch.cat([e[k] for e in lst])
+    for k in ("weights", "rgbs", "ray_indices", "t_starts"):
+        assert torch.equal(cat(a[4], k), cat(b[4], k)), k
+    # work: one field evaluation per processed sample; the march holds several times the kept samples
+    o = rays.origins.reshape(-1, 3).contiguous(); d = rays.viewdirs.reshape(-1, 3).contiguous()
+    t0, t1, _, packed = est.march(o, d, near_plane=rk.get("near_plane", 0.0), far_plane=rk.get("far_plane", 1e10),
+                                  render_step_size=rk["render_step_size"], cone_angle=rk.get("cone_angle", 0.0))
+    out = ops.render_image_eval_native(f._descriptor(), o, d, packed, t0, t1, 1e-4, 0.0, ts.reshape(-1), False,
+                                       rk["render_bkgd"].reshape(-1).float().contiguous())
+    processed, iters = out[5]
+    assert a[3] <= processed <= int(1.35 * a[3]) and processed < t0.shape[0] // 2, (a[3], processed, t0.shape[0])
+    assert int(out[4][-1]) == a[3] and iters < 64
 
 
 def test_full_size_frame_properties(oracle, full_frame):
