@@ -141,14 +141,10 @@ __global__ __launch_bounds__(THREADS) void field_kernel(FieldArgs A)
         const int64_t nd = *A.n_dev;
         n_eff = nd < n_eff ? nd : n_eff;
     }
-    if (A.base_dev) {               // the call's window of persistent sample arrays (render_image: frame.hip)
-        const int64_t b = *A.base_dev;
-        if (A.ray_idx32) A.ray_idx32 += b;
-        if (A.ray_idx) A.ray_idx += b;
-        A.t0 += b; A.t1 += b;
-        A.sigma += b;
-        if (A.rgb) A.rgb += 3 * b;
-    }
+    // the call's window of persistent per-sample arrays (render_image, frame.hip): ray_idx / t0 / t1 / sigma / rgb
+    // entry s of the call is entry sbase + s of the arrays.  (Kept as an index offset: adding it to the pointers of
+    // the by-value argument block would make the compiler keep the whole block in scratch.)
+    const int64_t sbase = A.base_dev ? *A.base_dev : 0;
     const int64_t n_tiles = (n_eff + TILE - 1) / TILE;
     // a workgroup without a tile leaves before staging anything (launches are sized by a host-side upper bound of
     // the sample count; the exact count comes from device memory)
@@ -211,12 +207,12 @@ __global__ __launch_bounds__(THREADS) void field_kernel(FieldArgs A)
             if (A.rays_mode) {
                 // a negative ray index marks an unused sample slot (the frame renderer's slot-major sample layout):
                 // it is evaluated on ray 0 at t = 0 and its outputs land in its own, never-read slot
-                const int64_t r_in = A.ray_idx32 ? (int64_t)A.ray_idx32[s] : A.ray_idx[s];
+                const int64_t r_in = A.ray_idx32 ? (int64_t)A.ray_idx32[sbase + s] : A.ray_idx[sbase + s];
                 const bool used = r_in >= 0;
                 const int64_t r = used ? r_in : 0;
                 any_used = any_used || used;
                 ridx[j] = r;
-                const float tm2 = used ? A.t0[s] + A.t1[s] : 0.0f;
+                const float tm2 = used ? A.t0[sbase + s] + A.t1[sbase + s] : 0.0f;
 #pragma unroll
                 for (int a = 0; a < 3; ++a) px[j][a] = A.rays_o[3 * r + a] + (A.rays_d[3 * r + a] * tm2) / 2.0f;
                 tq[j] = A.t_per_ray ? A.timestamps[r] : A.timestamps[0];
@@ -385,7 +381,7 @@ __global__ __launch_bounds__(THREADS) void field_kernel(FieldArgs A)
             const int64_t s = tile * TILE + 16 * j + c;
             float sg = det_expf(D[j][0][0] - 1.0f);           // density = trunc_exp(raw - 1) * selector; raw: group 3, reg 0
             sg = sel[j] ? sg : 0.0f;
-            if (g == 3 && s < n_eff) A.sigma[s] = sg;
+            if (g == 3 && s < n_eff) A.sigma[sbase + s] = sg;
             if (A.geo && s < n_eff) {
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
@@ -436,7 +432,7 @@ __global__ __launch_bounds__(THREADS) void field_kernel(FieldArgs A)
                 asm volatile("" : "+v"(lane_now));
                 const int g_now = (lane_now >> 4) & 3;
                 const int64_t s_now = tile * TILE + 16 * j + (lane_now & 15);
-                if (g_now < 3 && s_now < n_eff) A.rgb[3 * s_now + g_now] = o1;
+                if (g_now < 3 && s_now < n_eff) A.rgb[3 * (sbase + s_now) + g_now] = o1;
             }
         }
     }

@@ -66,14 +66,10 @@ __global__ __launch_bounds__(THREADS) void field_half_kernel(FieldArgs A)
         const int64_t nd = *A.n_dev;
         n_eff = nd < n_eff ? nd : n_eff;
     }
-    if (A.base_dev) {               // the call's window of persistent sample arrays (render_image: frame.hip)
-        const int64_t b = *A.base_dev;
-        if (A.ray_idx32) A.ray_idx32 += b;
-        if (A.ray_idx) A.ray_idx += b;
-        A.t0 += b; A.t1 += b;
-        A.sigma += b;
-        if (A.rgb) A.rgb += 3 * b;
-    }
+    // the call's window of persistent per-sample arrays (render_image, frame.hip): ray_idx / t0 / t1 / sigma / rgb
+    // entry s of the call is entry sbase + s of the arrays.  (Kept as an index offset: adding it to the pointers of
+    // the by-value argument block would make the compiler keep the whole block in scratch.)
+    const int64_t sbase = A.base_dev ? *A.base_dev : 0;
     const int64_t n_tiles = (n_eff + TILE - 1) / TILE;
     // a workgroup without a tile leaves before staging anything (see field.hip)
     if ((A.spread_tiles ? (int64_t)blockIdx.x * 4 : (int64_t)blockIdx.x * WAVES) >= n_tiles) return;
@@ -113,12 +109,12 @@ __global__ __launch_bounds__(THREADS) void field_half_kernel(FieldArgs A)
             sidx[j] = s;
             if (A.rays_mode) {
                 // negative ray index = unused sample slot (see field.hip)
-                const int64_t r_in = A.ray_idx32 ? (int64_t)A.ray_idx32[s] : A.ray_idx[s];
+                const int64_t r_in = A.ray_idx32 ? (int64_t)A.ray_idx32[sbase + s] : A.ray_idx[sbase + s];
                 const bool used = r_in >= 0;
                 const int64_t r = used ? r_in : 0;
                 any_used = any_used || used;
                 ridx[j] = r;
-                const float tm2 = used ? A.t0[s] + A.t1[s] : 0.0f;
+                const float tm2 = used ? A.t0[sbase + s] + A.t1[sbase + s] : 0.0f;
 #pragma unroll
                 for (int a = 0; a < 3; ++a) px[j][a] = A.rays_o[3 * r + a] + (A.rays_d[3 * r + a] * tm2) / 2.0f;
                 tq[j] = A.t_per_ray ? A.timestamps[r] : A.timestamps[0];
@@ -240,7 +236,7 @@ __global__ __launch_bounds__(THREADS) void field_half_kernel(FieldArgs A)
             const int64_t s = tile * TILE + 16 * j + c;
             float sg = fast_exp(D[j][0][3] - 1.0f);            // trunc_exp(raw - 1) * selector
             sg = sel[j] ? sg : 0.0f;
-            if (g == 3 && s < n_eff) A.sigma[s] = sg;
+            if (g == 3 && s < n_eff) A.sigma[sbase + s] = sg;
             if (A.geo && s < n_eff) {
 #pragma unroll
                 for (int r = 0; r < 4; ++r)
@@ -287,9 +283,9 @@ __global__ __launch_bounds__(THREADS) void field_half_kernel(FieldArgs A)
 #pragma unroll
                 for (int a = 0; a < 3; ++a) o3[a] = fast_rcp(1.0f + fast_exp(-D[j][0][a]));
                 if (g == 0 && s < n_eff) {
-                    A.rgb[3 * s] = o3[0];
-                    A.rgb[3 * s + 1] = o3[1];
-                    A.rgb[3 * s + 2] = o3[2];
+                    A.rgb[3 * (sbase + s)] = o3[0];
+                    A.rgb[3 * (sbase + s) + 1] = o3[1];
+                    A.rgb[3 * (sbase + s) + 2] = o3[2];
                 }
             }
         }
