@@ -108,6 +108,7 @@ PROTOTYPES = {
     "ced_render_frames_test": (C.c_int, [C.POINTER(FieldDesc), _i32, _i64, _vp, _vp, _vp, _i32, _i32, _vp, _vp, _f, _f, _f, _f,
                                          _f, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _vp, C.POINTER(_i64),
                                          C.POINTER(FrameTrace), _vp, _vp]),
+    "ced_march_all": (C.c_int, [_i64, _vp, _vp, _vp, _i32, _i32, _vp, _vp, _vp, _f, _f, _f, _i32, _vp, _vp, _vp, _vp, _vp]),
     "ced_render_image_workspace_bytes": (_i64, [_i64, _i64]),
     "ced_render_image": (C.c_int, [C.POINTER(FieldDesc), _i64, _vp, _vp, _i64, _vp, _vp, _vp, _f, _f, _vp, _i32, _vp, _vp, _vp,
                                    _vp, _vp, _vp, _i64, _vp, C.POINTER(_i64), _vp, _vp]),

@@ -657,6 +657,52 @@ __global__ __launch_bounds__(256) void image_gather_kernel(int64_t n, const int3
     }
 }
 
+// ------------------------------------------------------------------------------------------------------------------
+// One-shot march of every ray to the far plane (nerfacc traverse_grids without a step limit: the marching half of
+// OccGridEstimator.sampling, call sites cednerf/utils.py:115-125 and train_real.py:339-350) on the frame renderer's
+// accelerated walk: sphere tracing over the brick / cell distance fields through empty space, closed-form DDA re-entry,
+// the emitted samples those of the cell-by-cell walk bit for bit (march_accel.hpp).  Count pass -> caller's scan ->
+// fill pass, as ced_traverse_grids; one grid level (the multi-level case stays on ced_traverse_grids).
+struct MarchAllArgs {
+    int64_t n_rays;
+    const float *rays_o, *rays_d;
+    GridSpec grid;
+    AccelSpec accel;
+    const float *near_planes;
+    float far_plane;
+    int64_t *packed;               // [n_rays, 2]: FILL reads the first sample, COUNT writes the count
+    float *t_starts, *t_ends;
+    int64_t *ray_indices;          // optional
+};
+
+template <bool FILL>
+__global__ __launch_bounds__(kMarchThreads, 4) void march_all_kernel(MarchAllArgs A)
+{
+    const int64_t r = (int64_t)blockIdx.x * kMarchThreads + threadIdx.x;
+    if (r >= A.n_rays) return;
+    float o[3], d[3];
+#pragma unroll
+    for (int a = 0; a < 3; ++a) { o[a] = A.rays_o[3 * r + a]; d[a] = A.rays_d[3 * r + a]; }
+    float t_term;
+    if constexpr (!FILL) {
+        const int n = traverse_ray_frame<kFrameLook, true>(A.grid, A.accel, true, o, d, A.near_planes[r], A.far_plane, nullptr,
+                                                           nullptr, nullptr, [](int, float, float) {}, t_term);
+        A.packed[2 * r + 1] = n;
+    } else {
+        const int64_t start = A.packed[2 * r];
+        if (A.packed[2 * r + 1] == 0) return;
+        float *const p0 = A.t_starts + start, *const p1 = A.t_ends + start;
+        int64_t *const pr = A.ray_indices ? A.ray_indices + start : nullptr;
+        (void)traverse_ray_frame<kFrameLook, true>(A.grid, A.accel, true, o, d, A.near_planes[r], A.far_plane, nullptr, nullptr,
+                                                   nullptr,
+                                                   [&](int i, float t0, float t1) {
+                                                       p0[i] = t0; p1[i] = t1;
+                                                       if (pr) pr[i] = r;
+                                                   },
+                                                   t_term);
+    }
+}
+
 static inline size_t align_up(size_t x) { return (x + 255) & ~(size_t)255; }
 
 struct FrameWorkspace {
@@ -1164,4 +1210,26 @@ extern "C" int ced_render_image_gather(int64_t n_rays, int64_t n_all, int64_t pr
                        W.ridx, W.t0, W.t1, W.sigma, W.rgbs, W.w, W.tr, W.al, ray_offsets, chunk_rays,
                        ced::ImageOut{ ray_indices, t_starts, t_ends, sigmas, rgbs, weights, trans, alphas });
     return ced::check_launch("render_image_gather");
+}
+
+
+extern "C" int ced_march_all(int64_t n_rays, const float *rays_o, const float *rays_d, const uint8_t *binaries,
+                             int32_t n_grids, int32_t res, const float *aabbs, const void *accel, const float *near_planes,
+                             float far_plane, float step_size, float cone_angle, int32_t fill, int64_t *packed_info,
+                             float *t_starts, float *t_ends, int64_t *ray_indices, void *stream)
+{
+    CED_REQUIRE(n_rays >= 0 && res >= 1 && res <= 1024, "march_all: bad sizes");
+    CED_REQUIRE(n_grids == 1, "march_all: one grid level only (use ced_traverse_grids for %d)", n_grids);
+    if (n_rays == 0) return CED_OK;
+    CED_REQUIRE(rays_o && rays_d && binaries && aabbs && accel && near_planes && packed_info, "march_all: null pointer");
+    CED_REQUIRE(!fill || (t_starts && t_ends), "march_all: fill pass without sample arrays");
+    ced::MarchAllArgs A{ n_rays, rays_o, rays_d,
+                         ced::GridSpec{ binaries, aabbs, 1, res, step_size, cone_angle, 0x7fffffff, nullptr },
+                         ced::accel_view(accel, 1, res, true), near_planes, far_plane, packed_info, t_starts, t_ends, ray_indices };
+    const dim3 grid((unsigned)((n_rays + ced::kMarchThreads - 1) / ced::kMarchThreads));
+    if (fill)
+        hipLaunchKernelGGL(ced::march_all_kernel<true>, grid, dim3(ced::kMarchThreads), 0, (hipStream_t)stream, A);
+    else
+        hipLaunchKernelGGL(ced::march_all_kernel<false>, grid, dim3(ced::kMarchThreads), 0, (hipStream_t)stream, A);
+    return ced::check_launch("march_all");
 }

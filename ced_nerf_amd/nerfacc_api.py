@@ -323,9 +323,11 @@ class OccGridEstimator(torch.nn.Module):
 
     @torch.no_grad()
     def march(self, rays_o, rays_d, near_plane: float = 0.0, far_plane: float = 1e10, t_min=None, t_max=None,
-              render_step_size: float = 1e-3, stratified: bool = False, cone_angle: float = 0.0):
+              render_step_size: float = 1e-3, stratified: bool = False, cone_angle: float = 0.0,
+              want_ray_indices: bool = True, fast: Optional[bool] = None):
         """The marching half of `sampling`: every sample inside occupied cells, all rays to the far plane.
-        Returns (t_starts, t_ends, ray_indices, packed_info)."""
+        Returns (t_starts, t_ends, ray_indices, packed_info).  fast: None = the accelerated one-level walk when it
+        applies, False = ced_traverse_grids."""
         rays_o = rays_o.contiguous(); rays_d = rays_d.contiguous()
         near_planes = torch.full_like(rays_o[..., 0], fill_value=near_plane)
         far_planes = torch.full_like(rays_o[..., 0], fill_value=far_plane)
@@ -335,6 +337,11 @@ class OccGridEstimator(torch.nn.Module):
             far_planes = torch.clamp(far_planes, max=t_max)
         if stratified:
             near_planes = near_planes + torch.rand_like(near_planes) * render_step_size
+        if fast is None:
+            fast = self.binaries.shape[0] == 1 and t_max is None and rays_o.is_cuda
+        if fast:        # one grid level: the accelerated walk of the frame renderer (same samples, ced_march_all)
+            return ops.march_all(rays_o, rays_d, self.binaries, self.aabbs, self.occupancy_accel(), near_planes.contiguous(),
+                                 far_plane, render_step_size, cone_angle, want_ray_indices=want_ray_indices)
         t_starts, t_ends, ray_indices, packed_info, _ = march_packed(
             rays_o, rays_d, self.binaries, self.aabbs, near_planes.contiguous(), far_planes.contiguous(),
             render_step_size, cone_angle)

@@ -532,6 +532,34 @@ def render_image_test_native(desc: _lib.FieldDesc, rays_o, rays_d, binaries, aab
     return rgb, opacity, depth, int(total.value)
 
 
+def march_all(rays_o, rays_d, binaries, aabbs, accel, near_planes, far_plane: float, step_size: float, cone_angle: float,
+              want_ray_indices: bool = True):
+    """ced_march_all: every ray marched to the far plane on the accelerated walk (one grid level).
+    Returns (t_starts, t_ends, ray_indices or None, packed_info [n,2])."""
+    _chk(rays_o, torch.float32, "rays_o"); _chk(rays_d, torch.float32, "rays_d")
+    _chk(aabbs, torch.float32, "aabbs"); _chk(near_planes, torch.float32, "near_planes")
+    assert binaries.is_cuda and binaries.is_contiguous() and binaries.ndim == 4 and binaries.shape[0] == 1
+    assert accel is not None and accel.is_cuda
+    n = rays_o.shape[0]
+    res = binaries.shape[1]
+    dev = rays_o.device
+    L = _lib.lib()
+    packed = torch.zeros((n, 2), device=dev, dtype=torch.int64)
+    args = (n, _p(rays_o), _p(rays_d), _p(_as_u8(binaries)), 1, res, _p(aabbs), _p(accel), _p(near_planes), float(far_plane),
+            float(step_size), float(cone_angle))
+    _lib.check(L.ced_march_all(*args, 0, _p(packed), None, None, None, _stream()), "march_all (count)")
+    counts = packed[:, 1]
+    incl = torch.cumsum(counts, 0)
+    packed[:, 0] = incl - counts
+    total = int(incl[-1].item()) if n > 0 else 0
+    t_starts = torch.empty((total,), device=dev, dtype=torch.float32)
+    t_ends = torch.empty((total,), device=dev, dtype=torch.float32)
+    ray_indices = torch.empty((total,), device=dev, dtype=torch.int64) if want_ray_indices else None
+    if total > 0:
+        _lib.check(L.ced_march_all(*args, 1, _p(packed), _p(t_starts), _p(t_ends), _p(ray_indices), _stream()), "march_all (fill)")
+    return t_starts, t_ends, ray_indices, packed
+
+
 _image_ws: Dict[tuple, tuple] = {}
 
 

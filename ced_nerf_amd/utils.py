@@ -109,7 +109,7 @@ def render_image(
         if native:
             t_all0, t_all1, _, packed_all = estimator.march(
                 chunk_rays.origins, chunk_rays.viewdirs, near_plane=near_plane, far_plane=far_plane,
-                render_step_size=render_step_size, stratified=False, cone_angle=cone_angle)
+                render_step_size=render_step_size, stratified=False, cone_angle=cone_angle, want_ray_indices=False)
             thre = float(alpha_thre)
             if thre > 0.0:                                      # nerfacc: alpha_thre = min(alpha_thre, occs.mean())
                 thre = min(thre, estimator.occs.mean().item())

@@ -455,6 +455,17 @@ int ced_render_image_gather(int64_t n_rays, int64_t n_all, int64_t processed, co
                             int64_t *ray_indices, float *t_starts, float *t_ends, float *sigmas, float *rgbs,
                             float *weights, float *trans, float *alphas, void *stream);
 
+/* One-shot march of every ray to the far plane on the accelerated walk of the frame renderer: the samples of
+ * nerfacc.traverse_grids without a step limit (the marching half of OccGridEstimator.sampling, call sites
+ * cednerf/utils.py:115-125, train_real.py:339-350), bit for bit, 3x faster than ced_traverse_grids through empty space.
+ * One grid level only (n_grids == 1; more: ced_traverse_grids).  accel: ced_build_occupancy_accel's structure.
+ * fill = 0: packed_info[r][1] = samples of ray r.  The caller scans the counts into packed_info[r][0].
+ * fill = 1: writes t_starts / t_ends (and ray_indices, optional) of ray r from packed_info[r][0] on. */
+int ced_march_all(int64_t n_rays, const float *rays_o, const float *rays_d, const uint8_t *binaries, int32_t n_grids,
+                  int32_t res, const float *aabbs, const void *accel, const float *near_planes, float far_plane,
+                  float render_step_size, float cone_angle, int32_t fill, int64_t *packed_info, float *t_starts,
+                  float *t_ends, int64_t *ray_indices, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

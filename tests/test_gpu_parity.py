@@ -718,6 +718,24 @@ def full_frame(oracle):
     return sc, of, oest, f, est, rays, rk
 
 
+def test_full_size_one_shot_march_on_the_accelerated_walk(oracle, full_frame):
+    """ced_march_all (sphere-traced one-shot march, one grid level) against ced_traverse_grids on all 640 000 rays of
+    config 2: counts, starts and every sample bit for bit -- with the frame's near plane and with per-ray (stratified)
+    near planes, as the training step marches."""
+    sc, of, oest, f, est, rays, rk = full_frame
+    o = rays.origins.reshape(-1, 3).contiguous(); d = rays.viewdirs.reshape(-1, 3).contiguous()
+    for stratified in (False, True):
+        torch.manual_seed(3)
+        a = est.march(o, d, near_plane=rk["near_plane"], far_plane=rk["far_plane"], render_step_size=rk["render_step_size"],
+                      cone_angle=rk["cone_angle"], stratified=stratified, fast=True)
+        torch.manual_seed(3)
+        b = est.march(o, d, near_plane=rk["near_plane"], far_plane=rk["far_plane"], render_step_size=rk["render_step_size"],
+                      cone_angle=rk["cone_angle"], stratified=stratified, fast=False)
+        assert a[0].shape[0] > 10_000_000
+        for x, y, nm in zip(a, b, ("t_starts", "t_ends", "ray_indices", "packed_info")):
+            assert x.dtype == y.dtype and torch.equal(x, y), (nm, stratified)
+
+
 def test_full_size_render_image_native_pass(oracle, full_frame):
     """800x800 (BASELINE config 2): render_image through ced_render_image equals the staged composition in every pixel
     and every per-sample array, and evaluates the field on far fewer samples than the march holds."""

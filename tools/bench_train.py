@@ -13,7 +13,7 @@ opt = torch.optim.Adam(field.parameters(), lr=1e-3)
 o = T(sc["origins"]).reshape(-1, 3); d = T(sc["viewdirs"]).reshape(-1, 3); ts = T(sc["timestamps"])
 bk = T(sc["render"]["render_bkgd"])
 g = torch.Generator(device=dev).manual_seed(0)
-for n_rays in (16384, 65536, 262144):
+for n_rays in [int(v) for v in os.environ.get("N_RAYS", "16384,65536,262144").split(",")]:
     target = torch.rand(n_rays, 3, device=dev, generator=g)
     samples = []
     for it in range(8):
