@@ -472,9 +472,11 @@ __global__ __launch_bounds__(256) void image_prep_kernel(int64_t n_rays, ImageSt
     int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (r >= n_rays) return;
     st.cursor[r] = 0; st.acc_all[r] = 0.0f; st.acc_kept[r] = 0.0f; st.kept[r] = 0;
-    rgb[3 * r] = 0.0f; rgb[3 * r + 1] = 0.0f; rgb[3 * r + 2] = 0.0f;
-    opacity[r] = 0.0f;
-    depth[r] = 0.0f;
+    if (rgb) {
+        rgb[3 * r] = 0.0f; rgb[3 * r + 1] = 0.0f; rgb[3 * r + 2] = 0.0f;
+        opacity[r] = 0.0f;
+        depth[r] = 0.0f;
+    }
 }
 
 // The iteration's samples: the next `limit` samples of every alive ray, copied from the one-shot march into the
@@ -536,6 +538,7 @@ __global__ __launch_bounds__(kMarchThreads) void image_chunk_kernel(
 // Visibility (nerfacc render_visibility_from_density: exp(-sum so far) >= early_stop_eps, alpha >= alpha_thre), weights
 // of the kept samples (render_weight_from_density over the kept ones only) and the three per-ray sums of
 // cednerf/render.py:158-169 -- every sum sequential in sample order, carried across iterations in the ray's state.
+template <bool FULL>
 __global__ __launch_bounds__(kCompositeThreads) void image_composite_kernel(
     IterPlan *plan, const int32_t *__restrict__ alive_list, int32_t *__restrict__ next_list,
     const int32_t *__restrict__ packed, const int64_t *__restrict__ packed_all, const float *__restrict__ t0,
@@ -558,7 +561,8 @@ __global__ __launch_bounds__(kCompositeThreads) void image_composite_kernel(
             const int64_t sb = packed[2 * r];
             cnt = packed[2 * r + 1];
             if (cnt > 0) {
-                float c0 = rgb[3 * r], c1 = rgb[3 * r + 1], c2 = rgb[3 * r + 2], op = opacity[r], dp = depth[r];
+                float c0 = 0.0f, c1 = 0.0f, c2 = 0.0f, op = 0.0f, dp = 0.0f;
+                if constexpr (FULL) { c0 = rgb[3 * r]; c1 = rgb[3 * r + 1]; c2 = rgb[3 * r + 2]; op = opacity[r]; dp = depth[r]; }
                 float acc = st.acc_all[r], acck = st.acc_kept[r];
                 int kept = st.kept[r];
                 bool open = true;                   // false once a sample failed the transmittance test: the rest fail too
@@ -570,7 +574,7 @@ __global__ __launch_bounds__(kCompositeThreads) void image_composite_kernel(
                     for (int u = 0; u < kU; ++u) {
                         const int64_t j = i + u < end ? i + u : end - 1;
                         ts[u] = t0[j]; te[u] = t1[j]; sg[u] = sig[j];
-                        cr[u] = rgbs[3 * j]; cg[u] = rgbs[3 * j + 1]; cb[u] = rgbs[3 * j + 2];
+                        if constexpr (FULL) { cr[u] = rgbs[3 * j]; cg[u] = rgbs[3 * j + 1]; cb[u] = rgbs[3 * j + 2]; }
                     }
 #pragma unroll
                     for (int u = 0; u < kU; ++u) {
@@ -583,23 +587,27 @@ __global__ __launch_bounds__(kCompositeThreads) void image_composite_kernel(
                         acc = acc + sd;
                         int rank = -1;
                         if (vis) {
-                            const float t = alpha_thre > 0.0f ? det_expf(-acck) : tv;   // no alpha test: the two sums coincide
-                            const float w = t * a;
-                            c0 = c0 + w * cr[u];
-                            c1 = c1 + w * cg[u];
-                            c2 = c2 + w * cb[u];
-                            op = op + w;
-                            dp = dp + w * ((ts[u] + te[u]) / 2.0f);
-                            acck = acck + sd;
-                            w_out[i + u] = w; tr_out[i + u] = t; al_out[i + u] = a;
+                            if constexpr (FULL) {
+                                const float t = alpha_thre > 0.0f ? det_expf(-acck) : tv;   // no alpha test: the two sums coincide
+                                const float w = t * a;
+                                c0 = c0 + w * cr[u];
+                                c1 = c1 + w * cg[u];
+                                c2 = c2 + w * cb[u];
+                                op = op + w;
+                                dp = dp + w * ((ts[u] + te[u]) / 2.0f);
+                                acck = acck + sd;
+                                w_out[i + u] = w; tr_out[i + u] = t; al_out[i + u] = a;
+                            }
                             rank = kept++;
                         }
                         rank_out[i + u] = rank;
                     }
                 }
-                rgb[3 * r] = c0; rgb[3 * r + 1] = c1; rgb[3 * r + 2] = c2;
-                opacity[r] = op;
-                depth[r] = dp;
+                if constexpr (FULL) {
+                    rgb[3 * r] = c0; rgb[3 * r + 1] = c1; rgb[3 * r + 2] = c2;
+                    opacity[r] = op;
+                    depth[r] = dp;
+                }
                 const int cur = st.cursor[r] + cnt;
                 st.cursor[r] = cur;
                 st.acc_all[r] = acc; st.acc_kept[r] = acck; st.kept[r] = kept;
@@ -651,9 +659,12 @@ __global__ __launch_bounds__(256) void image_gather_kernel(int64_t n, const int3
         const int64_t r = ridx[i];
         const int64_t d = ray_offset[r] + k;
         out.ray_indices[d] = chunk_rays > 0 ? r % chunk_rays : r;
-        out.t_starts[d] = t0[i]; out.t_ends[d] = t1[i]; out.sigmas[d] = sig[i];
-        out.rgbs[3 * d] = rgbs[3 * i]; out.rgbs[3 * d + 1] = rgbs[3 * i + 1]; out.rgbs[3 * d + 2] = rgbs[3 * i + 2];
-        out.weights[d] = w[i]; out.trans[d] = tr[i]; out.alphas[d] = al[i];
+        out.t_starts[d] = t0[i]; out.t_ends[d] = t1[i];
+        if (out.sigmas) out.sigmas[d] = sig[i];
+        if (out.rgbs) {                       // (NULL after a sampling-only call: those arrays were never written)
+            out.rgbs[3 * d] = rgbs[3 * i]; out.rgbs[3 * d + 1] = rgbs[3 * i + 1]; out.rgbs[3 * d + 2] = rgbs[3 * i + 2];
+            out.weights[d] = w[i]; out.trans[d] = tr[i]; out.alphas[d] = al[i];
+        }
     }
 }
 
@@ -1026,8 +1037,9 @@ static int render_image_impl(const ced_field_desc *field, int64_t n_rays, const 
     CED_REQUIRE(n_rays < (1ll << 31) / 4 && n_all < (1ll << 31) - 128, "%s: too many rays / samples for 32-bit indices", who);
     if (stats_out) { stats_out[0] = 0; stats_out[1] = 0; stats_out[2] = 0; }
     if (n_rays == 0) return CED_OK;
-    CED_REQUIRE(rays_o && rays_d && packed_all && (n_all == 0 || (t0_all && t1_all)) && timestamps && rgb && opacity &&
-                    depth && kept && workspace && host_stats,
+    const bool full = rgb != nullptr;               // rgb == NULL: sampling only (density-only field, no pixel sums)
+    CED_REQUIRE(rays_o && rays_d && packed_all && (n_all == 0 || (t0_all && t1_all)) && timestamps && kept && workspace &&
+                    host_stats && (!full || (opacity && depth)),
                 "%s: null pointer", who);
     const int64_t cap = image_capacity(n_rays, n_all);
     ImageWorkspace W = carve_image(workspace, n_rays, cap);
@@ -1079,8 +1091,8 @@ static int render_image_impl(const ced_field_desc *field, int64_t n_rays, const 
         F.rays_o = rays_o; F.rays_d = rays_d; F.ray_idx32 = W.ridx;
         F.t0 = W.t0; F.t1 = W.t1;
         F.timestamps = timestamps;
-        F.rays_mode = 1; F.t_per_ray = t_per_ray ? 1 : 0; F.want_rgb = 1;
-        F.rgb = W.rgbs; F.sigma = W.sigma; F.geo = nullptr;
+        F.rays_mode = 1; F.t_per_ray = t_per_ray ? 1 : 0; F.want_rgb = full ? 1 : 0;
+        F.rgb = full ? W.rgbs : nullptr; F.sigma = W.sigma; F.geo = nullptr;
         rc = launch_field(field, F, (void *)stream);
         if (rc) return rc;
         int64_t cgrid = (alive_bound + kCompositeThreads - 1) / kCompositeThreads;
@@ -1088,16 +1100,22 @@ static int render_image_impl(const ced_field_desc *field, int64_t n_rays, const 
         if (cgrid < 1) cgrid = 1;
         seq = ++g_publish_seq;
         seq_of[it] = seq;
-        hipLaunchKernelGGL(image_composite_kernel, dim3((unsigned)cgrid), dim3(kCompositeThreads), 0, stream, plan, cur_list,
-                           next_list, W.packed, packed_all, W.t0, W.t1, W.sigma, W.rgbs, W.st, W.w, W.tr, W.al, W.rank, rgb,
-                           opacity, depth, early_stop_eps, alpha_thre);
+        if (full)
+            hipLaunchKernelGGL(image_composite_kernel<true>, dim3((unsigned)cgrid), dim3(kCompositeThreads), 0, stream, plan,
+                               cur_list, next_list, W.packed, packed_all, W.t0, W.t1, W.sigma, W.rgbs, W.st, W.w, W.tr, W.al,
+                               W.rank, rgb, opacity, depth, early_stop_eps, alpha_thre);
+        else
+            hipLaunchKernelGGL(image_composite_kernel<false>, dim3((unsigned)cgrid), dim3(kCompositeThreads), 0, stream, plan,
+                               cur_list, next_list, W.packed, packed_all, W.t0, W.t1, W.sigma, (const float *)nullptr, W.st,
+                               (float *)nullptr, (float *)nullptr, (float *)nullptr, W.rank, (float *)nullptr,
+                               (float *)nullptr, (float *)nullptr, early_stop_eps, alpha_thre);
         hipLaunchKernelGGL(frame_schedule_kernel, dim3(1), dim3(64), 0, stream,
                            ScheduleArgs{ W.plans, it, 1, (int)n_rays, 1, big, (long long *)host_stats, seq });
         rc = check_launch("render_image (iteration)");
         if (rc) return rc;
     }
     const int enqueued = it;
-    hipLaunchKernelGGL(frame_finalize_kernel, grd, blk, 0, stream, n_rays, bkgd, rgb, opacity, depth);
+    if (full) hipLaunchKernelGGL(frame_finalize_kernel, grd, blk, 0, stream, n_rays, bkgd, rgb, opacity, depth);
     rc = check_launch("render_image (finalize)");
     if (rc) return rc;
     std::vector<IterPlan> plans((size_t)enqueued + 1);
@@ -1199,8 +1217,9 @@ extern "C" int ced_render_image_gather(int64_t n_rays, int64_t n_all, int64_t pr
 {
     CED_REQUIRE(n_rays >= 0 && n_all >= 0 && processed >= 0, "render_image_gather: bad sizes");
     if (processed == 0) return CED_OK;
-    CED_REQUIRE(workspace && ray_offsets && ray_indices && t_starts && t_ends && sigmas && rgbs && weights && trans && alphas,
-                "render_image_gather: null pointer");
+    CED_REQUIRE(workspace && ray_offsets && ray_indices && t_starts && t_ends, "render_image_gather: null pointer");
+    CED_REQUIRE((rgbs && weights && trans && alphas) || (!rgbs && !weights && !trans && !alphas),
+                "render_image_gather: rgbs / weights / trans / alphas go together");
     const ced::ImageWorkspace W = ced::carve_image(const_cast<void *>(workspace), n_rays, ced::image_capacity(n_rays, n_all));
     CED_REQUIRE((int64_t)W.bytes <= workspace_bytes && processed <= ced::image_capacity(n_rays, n_all),
                 "render_image_gather: workspace does not match");

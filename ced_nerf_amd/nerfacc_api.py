@@ -350,9 +350,25 @@ class OccGridEstimator(torch.nn.Module):
     def sampling(self, rays_o, rays_d, sigma_fn: Optional[Callable] = None, alpha_fn: Optional[Callable] = None,
                  near_plane: float = 0.0, far_plane: float = 1e10, t_min=None, t_max=None,
                  render_step_size: float = 1e-3, early_stop_eps: float = 1e-4, alpha_thre: float = 0.0,
-                 stratified: bool = False, cone_angle: float = 0.0) -> Tuple[torch.Tensor, torch.Tensor, torch.Tensor]:
+                 stratified: bool = False, cone_angle: float = 0.0,
+                 sigma_field=None) -> Tuple[torch.Tensor, torch.Tensor, torch.Tensor]:
+        """nerfacc OccGridEstimator.sampling (call sites cednerf/utils.py:115-125, train_real.py:339-350).
+        sigma_field = (field, timestamps, per_ray): says that `sigma_fn` IS the density of that HIP field
+        (`field.query_rays(..., want_rgb=False)`); the visibility filter then runs on ced_render_image's sampling-only
+        mode -- density evaluated front to back, rays stopped at the threshold -- with the survivors of the filter over
+        every marched sample, bit for bit (tests/test_gpu_parity.py)."""
+        native = (sigma_field is not None and rays_o.is_cuda and (alpha_thre > 0.0 or early_stop_eps > 0.0)
+                  and early_stop_eps > 0.0)
         t_starts, t_ends, ray_indices, packed_info = self.march(rays_o, rays_d, near_plane, far_plane, t_min, t_max,
-                                                                render_step_size, stratified, cone_angle)
+                                                                render_step_size, stratified, cone_angle,
+                                                                want_ray_indices=not native)
+        if native:
+            fld, ts, per_ray = sigma_field
+            thre = float(alpha_thre)
+            if thre > 0.0:
+                thre = min(thre, self.occs.mean().item())
+            return ops.sampling_native(fld._descriptor(), rays_o.contiguous(), rays_d.contiguous(), packed_info, t_starts,
+                                       t_ends, early_stop_eps, thre, ts.reshape(-1).float().contiguous(), per_ray)
         if (alpha_thre > 0.0 or early_stop_eps > 0.0) and (sigma_fn is not None or alpha_fn is not None):
             alpha_thre = min(alpha_thre, self.occs.mean().item())
             if alpha_fn is not None:

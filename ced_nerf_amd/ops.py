@@ -618,6 +618,49 @@ def render_image_eval_native(desc: _lib.FieldDesc, rays_o, rays_d, packed_info, 
     return rgb, opacity, depth, extras, offsets, (processed, int(stats[1]))
 
 
+def sampling_native(desc: _lib.FieldDesc, rays_o, rays_d, packed_info, t_starts, t_ends, early_stop_eps, alpha_thre,
+                    timestamps, t_per_ray, max_workgroups: int = 0):
+    """The visibility filter of OccGridEstimator.sampling (sigma_fn = the fused field) on ced_render_image's
+    sampling-only mode: density evaluated front to back, rays stopped at the transmittance threshold.
+    Returns the surviving (ray_indices, t_starts, t_ends) -- those of the filter over every marched sample."""
+    _chk(rays_o, torch.float32, "rays_o"); _chk(rays_d, torch.float32, "rays_d")
+    _chk(packed_info, torch.int64, "packed_info"); _chk(t_starts, torch.float32, "t_starts")
+    _chk(t_ends, torch.float32, "t_ends"); _chk(timestamps, torch.float32, "timestamps")
+    n = rays_o.shape[0]
+    n_all = t_starts.shape[0]
+    assert packed_info.shape == (n, 2) and t_ends.shape == (n_all,)
+    if t_per_ray:
+        assert timestamps.numel() == n, "per-ray timestamps must have one entry per ray"
+    dev = rays_o.device
+    L = _lib.lib()
+    need = int(L.ced_render_image_workspace_bytes(n, n_all))
+    key = (dev.index, torch.cuda.current_stream().cuda_stream)
+    with _frame_ws_lock:
+        ws = _image_ws.get(key)
+        if ws is None or ws[0].numel() < need:
+            ws = (torch.empty((max(need, 1),), device=dev, dtype=torch.uint8),
+                  ws[1] if ws is not None else torch.zeros((512,), dtype=torch.int64).pin_memory())
+            _image_ws[key] = ws
+    kept = torch.empty((n,), device=dev, dtype=torch.int32)
+    stats = (C.c_int64 * 3)()
+    rc = L.ced_render_image(C.byref(_with_workgroups(desc, max_workgroups)), n, _p(rays_o), _p(rays_d), n_all,
+                            _p(packed_info), _p(t_starts), _p(t_ends), float(early_stop_eps), float(alpha_thre),
+                            _p(timestamps), int(bool(t_per_ray)), None, None, None, None, _p(kept),
+                            _p(ws[0]), ws[0].numel(), C.c_void_p(ws[1].data_ptr()), stats, None, _stream())
+    _lib.check(rc, "render_image (sampling)")
+    offsets = torch.zeros((n + 1,), device=dev, dtype=torch.int64)
+    torch.cumsum(kept, 0, out=offsets[1:])
+    total = int(offsets[-1].item()) if n > 0 else 0
+    ray_indices = torch.empty((total,), device=dev, dtype=torch.int64)
+    t0 = torch.empty((total,), device=dev, dtype=torch.float32)
+    t1 = torch.empty((total,), device=dev, dtype=torch.float32)
+    if total > 0:
+        rc = L.ced_render_image_gather(n, n_all, int(stats[0]), _p(ws[0]), ws[0].numel(), _p(offsets), 0, _p(ray_indices),
+                                       _p(t0), _p(t1), None, None, None, None, None, _stream())
+        _lib.check(rc, "render_image_gather (sampling)")
+    return ray_indices, t0, t1
+
+
 def render_frames_test_native(desc: _lib.FieldDesc, n_frames: int, rays_o, rays_d, binaries, aabbs, near_plane, far_plane,
                               render_step_size, cone_angle, early_stop_eps, max_samples, frame_times, bkgd,
                               tracer: Optional[FrameTracer] = None, field_stream: Optional[torch.cuda.Stream] = None,

@@ -242,7 +242,7 @@ def refresh_occupancy(field: TrainableField, estimator, step: int, timestamps: t
 def train_step(field: TrainableField, estimator, optimizer, rays_o: torch.Tensor, rays_d: torch.Tensor,
                timestamps: torch.Tensor, target_rgb: torch.Tensor, render_step_size: float, near_plane: float = 0.0,
                far_plane: float = 1e10, cone_angle: float = 0.0, alpha_thre: float = 0.0,
-               render_bkgd: Optional[torch.Tensor] = None, grad_scaler=None) -> Dict:
+               render_bkgd: Optional[torch.Tensor] = None, grad_scaler=None, native_sampling: bool = True) -> Dict:
     """One optimisation step on a batch of rays (train_real.py:339-380): stratified occupancy-grid sampling with the
     current density (no gradient), differentiable field + compositing, smooth-L1 colour loss, optimiser step."""
     n_rays = rays_o.shape[0]
@@ -258,9 +258,11 @@ def train_step(field: TrainableField, estimator, optimizer, rays_o: torch.Tensor
         _, sigma = fused.query_rays(rays_o, rays_d, ray_indices, t_starts, t_ends, ts, want_rgb=False)
         return sigma
 
+    fused.train()
     ray_indices, t_starts, t_ends = estimator.sampling(rays_o, rays_d, sigma_fn=sigma_fn, near_plane=near_plane,
                                                        far_plane=far_plane, render_step_size=render_step_size,
-                                                       stratified=True, cone_angle=cone_angle, alpha_thre=alpha_thre)
+                                                       stratified=True, cone_angle=cone_angle, alpha_thre=alpha_thre,
+                                                       sigma_field=(fused, ts, True) if native_sampling else None)
 
     with_heads = field.use_feat_predict or field.use_weight_predict
 

@@ -443,7 +443,11 @@ int ced_render_frames_test(const ced_field_desc *field, int32_t n_frames, int64_
  * ced_render_image_gather then writes the per-sample `extras` of the kept samples in the reference's order (by ray,
  * then along the ray): ray_offsets [n_rays] = exclusive prefix sum of `kept` (int64), outputs of sum(kept) entries;
  * chunk_rays > 0 makes ray_indices relative to the ray's chunk of that many rays (the reference's chunked eval loop,
- * cednerf/utils.py:108-133), 0 keeps them absolute. */
+ * cednerf/utils.py:108-133), 0 keeps them absolute.
+ * Sampling only (rgb == opacity == depth == NULL; the training step's `estimator.sampling(sigma_fn=...)`,
+ * train_real.py:339-350, per-ray timestamps): the field kernel evaluates the density alone and no pixel sums are formed;
+ * the gather then takes sigmas optional and rgbs == weights == trans == alphas == NULL and returns the surviving
+ * (ray_indices, t_starts, t_ends) of nerfacc's sampling, bit for bit. */
 int64_t ced_render_image_workspace_bytes(int64_t n_rays, int64_t n_all);
 int ced_render_image(const ced_field_desc *field, int64_t n_rays, const float *rays_o, const float *rays_d,
                      int64_t n_all, const int64_t *packed_info, const float *t_starts, const float *t_ends,

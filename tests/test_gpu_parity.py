@@ -1598,6 +1598,37 @@ def test_trainable_field_gradients_hip_vs_library(oracle):
         assert (a - b).abs().max().item() <= 2e-4 * b.abs().max().item(), (name, (a - b).abs().max().item(), b.abs().max().item())
 
 
+@pytest.mark.parametrize("name,alpha_thre", [("dnerf", 0.0), ("dnerf", 0.004), ("hypernerf", 0.0)])
+def test_sampling_on_the_native_visibility_pass(oracle, name, alpha_thre):
+    """OccGridEstimator.sampling as the training step calls it (stratified near planes, per-ray timestamps): the
+    sampling-only mode of ced_render_image (density front to back, rays stopped at the threshold) returns the survivors
+    of the filter over every marched sample, bit for bit."""
+    from ced_nerf_amd.nerfacc_api import OccGridEstimator
+    from ced_nerf_amd.train import TrainableField
+    sc = _scene(name, 96, 72, "trained", log2_hashmap_size=15)
+    cfg = sc["cfg"]
+    est = OccGridEstimator(cfg["aabb"], cfg["grid_resolution"], cfg["grid_levels"]).to(DEV)
+    est.set_binaries(T(sc["binaries"]))
+    fused = TrainableField(sc["params"], DEV).shared_inference()
+    fused.train()
+    o = T(sc["origins"]).reshape(-1, 3).contiguous(); d = T(sc["viewdirs"]).reshape(-1, 3).contiguous()
+    g = torch.Generator(device=DEV).manual_seed(4)
+    ts = torch.rand(o.shape[0], 1, device=DEV, generator=g)
+
+    def sigma_fn(t_starts, t_ends, ray_indices):
+        return fused.query_rays(o, d, ray_indices, t_starts, t_ends, ts, want_rgb=False)[1]
+
+    kw = dict(sigma_fn=sigma_fn, near_plane=cfg["near_plane"], far_plane=cfg["far_plane"],
+              render_step_size=cfg["render_step_size"], stratified=True, cone_angle=cfg["cone_angle"], alpha_thre=alpha_thre)
+    torch.manual_seed(9)
+    a = est.sampling(o, d, sigma_field=(fused, ts, True), **kw)
+    torch.manual_seed(9)
+    b = est.sampling(o, d, **kw)
+    assert b[0].numel() > 1000
+    for x, y, nm in zip(a, b, ("ray_indices", "t_starts", "t_ends")):
+        assert x.dtype == y.dtype and torch.equal(x, y), nm
+
+
 def test_training_steps_reduce_the_loss(oracle):
     """train.train_step end to end: HIP sampling, HIP hash forward/backward, HIP MLPs (ced_linear / ced_weight_grad),
     HIP compositing forward/backward, Adam.  A student whose hash table was damaged relearns a teacher's renders."""
