@@ -40,6 +40,9 @@ constexpr int kSlotAlign = 256;     // a frame's ray slots start at a multiple o
 #endif
 constexpr int kMarchThreads = CED_MARCH_THREADS;
 constexpr int kCompositeThreads = 256;
+#ifndef CED_COMPOSITE_KU
+#define CED_COMPOSITE_KU 4
+#endif
 constexpr int kHostLatticeWord = 8;    // host_stats: words 0..2 publish {alive, done, seq}; the lattice table from word 8 on
 
 // The plan of ONE iteration, in device memory (written by make_next_plan, read by that iteration's launches).
@@ -359,7 +362,7 @@ __global__ __launch_bounds__(kCompositeThreads) void frame_composite_kernel(
                 float acc = 0.0f;
                 // Samples are consumed strictly in order (the per-ray sums are sequential by contract), but
                 // their loads are issued kU at a time so one memory round trip feeds kU samples.
-                constexpr int kU = 4;
+                constexpr int kU = CED_COMPOSITE_KU;
                 int64_t i = sb;
                 const int64_t end = sb + cnt;
                 for (; i + kU <= end; i += kU) {
