@@ -556,6 +556,15 @@ def main():
                 timed0 = (o0["rgb"][0], o0["opacity"][0], o0["depth"][0])
             torch.cuda.synchronize()
             line["parity_vs_oracle"] = parity_vs_oracle(oracle_out, single, timed0, args.mlp_precision)
+            # the other arithmetic modes of `other_mlp_precisions`, same frame, same (fp32) oracle pixels: PSNR / max error
+            for prec in [p for p in args.also.split(",") if p and p != args.mlp_precision]:
+                field.set_mlp_precision(prec)
+                alt = render_image_test(args.max_samples, field, est, Rays(T(sc["origins"]), T(sc["viewdirs"])),
+                                        timestamps=ts, **rk)
+                torch.cuda.synchronize()
+                line.setdefault("other_mlp_precisions", {}).setdefault(prec, {})["parity_vs_oracle"] = parity_vs_oracle(
+                    oracle_out, alt, None, prec)
+            field.set_mlp_precision(args.mlp_precision)
         if args.torch_stride > 0:
             line["cpu_baseline_pytorch"] = cpu_baseline_pytorch(sc, args)
     print(json.dumps(line))
