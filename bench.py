@@ -216,6 +216,9 @@ def main():
         # HIP events around every field launch; one event set per timed step so nothing is read back
         # (hipEventElapsedTime) inside the timed region
         tracers.append([ops.FrameTracer(capacity=96, with_events=True) for _ in range(min(args.steps, 24))])
+        if os.environ.get("CED_BENCH_NO_STAMPS", "0") != "1":
+            for tr_ in tracers[-1]:
+                tr_.enable_device_stamps(dev)
         r.tracer = tracers[-1][0]
         lane_renderers.append(r)
     # multi-rank: the pixel all-gather of one step overlaps the next step's kernels (own stream, no read-back)
@@ -290,11 +293,13 @@ def main():
         window_rates.append(s_tot / d_w)
         timed += d_w
         n_extra += 1
-    intervals = []
+    intervals, intervals_dev = [], []
     for l in range(lanes):                      # the last min(steps, 24) steps' field launches
         for tr in tracers[l][:min(args.steps, len(tracers[l]))]:
             iv = tr.field_intervals(ref_event)
             intervals += iv
+            if tr.stamps is not None:
+                intervals_dev += [x for x in tr.field_intervals_device() if x is not None]
             field_ms[0] += sum(e - b for b, e in iv); field_launches[0] += len(iv)
             field_samples[0] += sum(it["n_new"] for it in tr.iterations())
     # time during which at least one field kernel was executing (frames in flight overlap their launches)
@@ -310,6 +315,22 @@ def main():
             cur_e = max(cur_e, e)
     if cur_e is not None:
         busy_ms += cur_e - cur_b
+    # the same from the kernel's own stamps (first workgroup in -> last workgroup out on the device wall clock): the
+    # time a field kernel was EXECUTING; an event pair also holds the launch's wait for CUs that the marching /
+    # compositing kernels of the other calls occupy
+    busy_dev_ms, raw_dev_ms = None, None
+    if intervals_dev:
+        intervals_dev.sort()
+        busy_dev_ms, cur_b, cur_e = 0.0, None, None
+        for b, e in intervals_dev:
+            if cur_e is None or b > cur_e:
+                if cur_e is not None:
+                    busy_dev_ms += cur_e - cur_b
+                cur_b, cur_e = b, e
+            else:
+                cur_e = max(cur_e, e)
+        busy_dev_ms += cur_e - cur_b
+        raw_dev_ms = sum(e - b for b, e in intervals_dev) / len(intervals_dev)
     prof = {"field": {"ms": field_ms[0], "launches": field_launches[0], "units": float(field_samples[0])}}
     tt = torch.tensor([dt, float(samples_local)], device=dev, dtype=torch.float64)
     if world > 1:
@@ -445,7 +466,10 @@ def main():
         # some field kernel was executing divided by the number of launches; the raw per-launch
         # average (what rocprofv3 --stats reports per dispatch) is kept beside it.
         raw_avg_ms = fk["ms"] / fk["launches"]
-        avg_ms = busy_ms / fk["launches"]
+        avg_events_ms = busy_ms / fk["launches"]
+        avg_ms = avg_events_ms
+        if busy_dev_ms is not None and len(intervals_dev) == fk["launches"]:
+            avg_ms = busy_dev_ms / fk["launches"]           # kernel-executing time (device stamps)
         samples_per_launch = fk["units"] / fk["launches"]
         tflops = samples_per_launch * ALG_FLOPS_PER_SAMPLE / (avg_ms * 1e-3) / 1e12
         gbs = samples_per_launch * (ALG_BYTES_PER_SAMPLE_F16 if fp16 else ALG_BYTES_PER_SAMPLE_F32) / (avg_ms * 1e-3) / 1e9
@@ -476,12 +500,20 @@ def main():
         kname = "field_kernel" if exact else "field_half_kernel"
         common = {"traffic_source": traffic_source,
                   "avg_launch_ms": avg_ms, "launches": fk["launches"], "samples_per_launch": samples_per_launch,
-                  "avg_launch_ms_raw": raw_avg_ms,
-                  "field_busy_over_wall": busy_ms / max(span_ms, 1e-9),
-                  "note": "%d call(s) in flight x %d frame(s) per call: avg_launch_ms = (time with a field kernel executing) "
-                          "/ launches; avg_launch_ms_raw = mean begin->end of a launch (overlapping launches share the chip; "
-                          "this is what rocprofv3 --stats lists); roofline_single_frame = the kernel with one frame alone"
-                          % (lanes, per_call)}
+                  "avg_launch_ms_raw": raw_dev_ms if raw_dev_ms is not None else raw_avg_ms,
+                  "timing": "device stamps" if avg_ms is not avg_events_ms else "hip events",
+                  "hip_events": {"avg_launch_ms": avg_events_ms, "avg_launch_ms_raw": raw_avg_ms,
+                                 "frac": (samples_per_launch * (ALG_FLOPS_PER_SAMPLE / 1e12 / PEAK_F32_MFMA_TFLOPS if args.mlp_precision == "f32"
+                                                                else (ALG_BYTES_PER_SAMPLE_F16 if fp16 else ALG_BYTES_PER_SAMPLE_F32) / 1e9 / PEAK_HBM_GBS)
+                                          / (avg_events_ms * 1e-3))},
+                  "field_busy_over_wall": (busy_dev_ms if busy_dev_ms is not None else busy_ms) / max(span_ms, 1e-9),
+                  "note": "%d call(s) in flight x %d frame(s) per call: avg_launch_ms = (time with a field kernel EXECUTING) "
+                          "/ launches, from the kernel's own stamps (first workgroup in -> last workgroup out, device wall "
+                          "clock); avg_launch_ms_raw = mean of those intervals per launch (overlapping launches share the "
+                          "chip; this is what rocprofv3 --stats lists per dispatch); hip_events = the same two figures from "
+                          "the HIP event pairs recorded around every launch on its stream, which also count the launch's "
+                          "wait for CUs held by the other calls' marching / compositing kernels; roofline_single_frame = the "
+                          "kernel with one frame alone (events)" % (lanes, per_call)}
         r_mfma = {"kernel": f"{kname} (fused DNGPradianceField forward, mlp_precision={args.mlp_precision})",
                   "bound": "mfma", "achieved": tflops, "peak": mfma_peak, "unit": "TFLOP/s", "frac": tflops / mfma_peak,
                   "traffic": traffic, "alg_flops_per_sample": ALG_FLOPS_PER_SAMPLE}

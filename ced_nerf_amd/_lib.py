@@ -50,7 +50,7 @@ class FrameTrace(C.Structure):
         ("capacity", C.c_int32), ("n_iters", C.c_int32),
         ("field_begin", C.POINTER(C.c_void_p)), ("field_end", C.POINTER(C.c_void_p)),
         ("iter_alive", C.POINTER(C.c_int64)), ("iter_n_samples", C.POINTER(C.c_int64)),
-        ("iter_samples", C.POINTER(C.c_int64)),
+        ("iter_samples", C.POINTER(C.c_int64)), ("field_stamps", C.c_void_p),
     ]
 
 
@@ -108,6 +108,7 @@ PROTOTYPES = {
     "ced_render_frames_test": (C.c_int, [C.POINTER(FieldDesc), _i32, _i64, _vp, _vp, _vp, _i32, _i32, _vp, _vp, _f, _f, _f, _f,
                                          _f, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _vp, C.POINTER(_i64),
                                          C.POINTER(FrameTrace), _vp, _vp]),
+    "ced_wall_clock_khz": (_i64, []),
     "ced_march_all": (C.c_int, [_i64, _vp, _vp, _vp, _i32, _i32, _vp, _vp, _vp, _f, _f, _f, _i32, _vp, _vp, _vp, _vp, _vp]),
     "ced_render_image_workspace_bytes": (_i64, [_i64, _i64]),
     "ced_render_image": (C.c_int, [C.POINTER(FieldDesc), _i64, _vp, _vp, _i64, _vp, _vp, _vp, _f, _f, _vp, _i32, _vp, _vp, _vp,

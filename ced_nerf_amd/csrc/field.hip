@@ -149,6 +149,7 @@ __global__ __launch_bounds__(THREADS) void field_kernel(FieldArgs A)
     // a workgroup without a tile leaves before staging anything (launches are sized by a host-side upper bound of
     // the sample count; the exact count comes from device memory)
     if ((A.spread_tiles ? (int64_t)blockIdx.x * 4 : (int64_t)blockIdx.x * FIELD_WAVES) >= n_tiles) return;
+    if (A.stamp && tid == 0) atomicMin(A.stamp, (unsigned long long)wall_clock64());
 
     // stage weights + level tables into LDS
     {
@@ -436,6 +437,9 @@ __global__ __launch_bounds__(THREADS) void field_kernel(FieldArgs A)
             }
         }
     }
+    // tracing only: every wave stamps its own end (waves of a workgroup finish up to a tile apart; a barrier here
+    // would hold the early ones' registers and cost 3 % of throughput)
+    if (A.stamp && lane == 0) atomicMax(A.stamp + 1, (unsigned long long)wall_clock64());
 }
 
 // ---- standalone hash-grid encode (one lane per point, all levels) ------------------------------

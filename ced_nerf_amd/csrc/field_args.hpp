@@ -9,6 +9,8 @@ namespace ced {
 struct FieldArgs {
     int64_t n;
     const int64_t *n_dev;                             // optional device-side sample count (<= n)
+    unsigned long long *stamp;                        // optional device {min start, max end} of the launch on the constant
+                                                      // wall clock (wall_clock64): first workgroup in, last workgroup out
     const int64_t *base_dev;                          // optional device-side first sample: the per-sample arrays of a
                                                       // rays-mode call (ray_idx32, t0, t1, rgb, sigma) start there
     const float *pos, *t, *dir;                       // explicit mode

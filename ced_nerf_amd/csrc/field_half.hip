@@ -73,6 +73,7 @@ __global__ __launch_bounds__(THREADS) void field_half_kernel(FieldArgs A)
     const int64_t n_tiles = (n_eff + TILE - 1) / TILE;
     // a workgroup without a tile leaves before staging anything (see field.hip)
     if ((A.spread_tiles ? (int64_t)blockIdx.x * 4 : (int64_t)blockIdx.x * WAVES) >= n_tiles) return;
+    if (A.stamp && tid == 0) atomicMin(A.stamp, (unsigned long long)wall_clock64());
 
     {
         const f4 *src = reinterpret_cast<const f4 *>(A.weights);
@@ -290,6 +291,9 @@ __global__ __launch_bounds__(THREADS) void field_half_kernel(FieldArgs A)
             }
         }
     }
+    // tracing only: every wave stamps its own end (waves of a workgroup finish up to a tile apart; a barrier here
+    // would hold the early ones' registers and cost 3 % of throughput)
+    if (A.stamp && lane == 0) atomicMax(A.stamp + 1, (unsigned long long)wall_clock64());
 }
 
 // Host: one layer into 16x16x32 A-fragment order.  Element (accumulator row p, operand position k) goes to

@@ -196,8 +196,13 @@ __device__ __forceinline__ void make_next_plan(const ScheduleArgs &S)
 
 // The plan of iteration 0.  The launch also brings the call's lattice table (256 floats the host wrote behind the
 // publish words of the pinned buffer, march_accel.hpp: build_lattice) into device memory.
-__global__ void frame_init_kernel(ScheduleArgs S, float *__restrict__ lattice_dev)
+__global__ void frame_init_kernel(ScheduleArgs S, float *__restrict__ lattice_dev, unsigned long long *stamps = nullptr,
+                                  int n_stamps = 0)
 {
+    for (int i = threadIdx.x; i < n_stamps; i += blockDim.x) {      // {min start, max end} per iteration
+        stamps[2 * i] = ~0ull;
+        stamps[2 * i + 1] = 0ull;
+    }
     if (lattice_dev) {
         const float *src = reinterpret_cast<const float *>(S.host + kHostLatticeWord);
         for (int i = threadIdx.x; i < 256; i += blockDim.x) lattice_dev[i] = src[i];
@@ -865,7 +870,9 @@ static int render_frames_impl(const ced_field_desc *field, int n_frames, int64_t
     hipLaunchKernelGGL(frame_init_kernel, dim3(1), dim3(64), 0, stream,
                        ScheduleArgs{ W.plans, -1, n_frames, (int)rays_per_frame, min_samples, (int)max_samples,
                                      (long long *)host_stats, seq },
-                       use_lattice ? W.lattice : (float *)nullptr);
+                       use_lattice ? W.lattice : (float *)nullptr,
+                       (unsigned long long *)(trace ? trace->field_stamps : nullptr),
+                       (trace && trace->field_stamps) ? (int)trace->capacity : 0);
     int rc = check_launch("render_image_test (prep)");
     if (rc) return rc;
 
@@ -918,6 +925,8 @@ static int render_frames_impl(const ced_field_desc *field, int n_frames, int64_t
         F.timestamps = frame_times ? W.ts_ray : timestamps;
         F.rays_mode = 1; F.t_per_ray = (frame_times || t_per_ray) ? 1 : 0; F.want_rgb = 1;
         F.rgb = W.rgbs; F.sigma = W.sigma; F.geo = nullptr;
+        if (trace && trace->field_stamps && it < trace->capacity)
+            F.stamp = reinterpret_cast<unsigned long long *>(trace->field_stamps) + 2 * it;
         if (split) {
             (void)hipEventRecord(ev_to_field[dev], stream);
             (void)hipStreamWaitEvent(fstream, ev_to_field[dev], 0);
@@ -1056,7 +1065,8 @@ static int render_image_impl(const ced_field_desc *field, int64_t n_rays, const 
     long long seq = ++g_publish_seq;
     const int big = 1 << 30;                               // no sample budget: the loop ends when no ray is alive
     hipLaunchKernelGGL(frame_init_kernel, dim3(1), dim3(64), 0, stream,
-                       ScheduleArgs{ W.plans, -1, 1, (int)n_rays, 1, big, (long long *)host_stats, seq }, (float *)nullptr);
+                       ScheduleArgs{ W.plans, -1, 1, (int)n_rays, 1, big, (long long *)host_stats, seq }, (float *)nullptr,
+                       (unsigned long long *)nullptr, 0);
     int rc = check_launch("render_image (prep)");
     if (rc) return rc;
     static const int run_ahead_env = [] {

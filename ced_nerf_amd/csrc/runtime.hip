@@ -17,4 +17,12 @@ void set_error(const char *fmt, ...)
 
 extern "C" int ced_version(void) { return 1; }
 
+extern "C" int64_t ced_wall_clock_khz(void)
+{
+    int dev = 0, khz = 0;
+    if (hipGetDevice(&dev) != hipSuccess) return -1;
+    if (hipDeviceGetAttribute(&khz, hipDeviceAttributeWallClockRate, dev) != hipSuccess) return -1;
+    return khz;
+}
+
 extern "C" const char *ced_last_error_string(void) { return ced::g_error; }

@@ -466,6 +466,25 @@ class FrameTracer:
             self.struct.field_begin = self._b
             self.struct.field_end = self._e
 
+        self.stamps = None
+
+    def enable_device_stamps(self, device) -> None:
+        """Have the field kernel itself stamp, per iteration, when its first workgroup started and its last one finished
+        (device wall clock): the interval the kernel was executing -- the event pair also counts its wait for CUs."""
+        self.stamps = torch.zeros((self.capacity, 2), device=device, dtype=torch.int64)
+        self.struct.field_stamps = C.c_void_p(self.stamps.data_ptr())
+
+    def field_intervals_device(self):
+        """(start, end) of every field launch in ms on the device wall clock (after the stream has been synchronised);
+        None for an iteration whose launch had no workgroup with work."""
+        n = min(int(self.struct.n_iters), self.capacity)
+        khz = int(_lib.lib().ced_wall_clock_khz())
+        st = self.stamps[:n].cpu().numpy().astype(np.uint64)
+        out = []
+        for a, b in st:
+            out.append(None if (a == np.uint64(0xffffffffffffffff) or b == 0) else (float(a) / khz, float(b) / khz))
+        return out
+
     def iterations(self):
         n = min(int(self.struct.n_iters), self.capacity)
         return [dict(n_alive=int(self._alive[i]), n_samples=int(self._nsamp[i]), n_new=int(self._samples[i]))

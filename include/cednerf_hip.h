@@ -371,7 +371,14 @@ typedef struct ced_frame_trace {
     int64_t *iter_alive;     /* out: rays alive entering iteration i (N_alive, cednerf/utils.py:231) */
     int64_t *iter_n_samples; /* out: samples per ray requested in iteration i (N_samples, utils.py:235) */
     int64_t *iter_samples;   /* out: samples marched and composited in iteration i */
+    uint64_t *field_stamps;  /* in: DEVICE memory [2 * capacity] or NULL.  Out (device): for iteration i the ticks
+                                {first workgroup of the field launch started, its last workgroup finished} on the
+                                device's constant wall clock (ced_wall_clock_khz ticks per ms): the interval the kernel
+                                was EXECUTING, where the event pair also counts its wait for free CUs */
 } ced_frame_trace;
+
+/* Rate of the device wall clock the field_stamps are taken on (hipDeviceAttributeWallClockRate), in kHz; < 0 on error. */
+int64_t ced_wall_clock_khz(void);
 
 /* Device bytes ced_render_image_test needs in `workspace` (negative on bad arguments). */
 int64_t ced_render_image_test_workspace_bytes(int64_t n_rays, int32_t n_grids, int32_t res, float cone_angle,

@@ -736,6 +736,28 @@ def test_full_size_one_shot_march_on_the_accelerated_walk(oracle, full_frame):
             assert x.dtype == y.dtype and torch.equal(x, y), (nm, stratified)
 
 
+def test_field_kernel_device_stamps(oracle, full_frame):
+    """ced_frame_trace.field_stamps: the field kernel's own {first workgroup in, last workgroup out} stamps lie inside
+    the HIP event pair recorded around the same launch and add up to most of it when the frame is alone on the chip."""
+    from ced_nerf_amd import ops
+    from ced_nerf_amd.utils import render_image_test
+    sc, of, oest, f, est, rays, rk = full_frame
+    ts = T(sc["timestamps"])
+    assert ops._lib.lib().ced_wall_clock_khz() > 1000
+    tracer = ops.FrameTracer(capacity=64, with_events=True)
+    tracer.enable_device_stamps(torch.device(DEV))
+    for _ in range(2):
+        render_image_test(1024, f, est, rays, timestamps=ts, tracer=tracer, **rk)
+    torch.cuda.synchronize()
+    ev = tracer.field_ms()
+    dv = tracer.field_intervals_device()
+    assert len(ev) == len(dv) >= 8 and all(x is not None for x in dv)
+    d_ms = [e - b for b, e in dv]
+    assert all(0.0 < d <= e * 1.02 + 0.01 for d, e in zip(d_ms, ev)), list(zip(d_ms, ev))
+    assert all(dv[i + 1][0] >= dv[i][1] for i in range(len(dv) - 1))            # launches of one stream, in order
+    assert sum(d_ms) > 0.8 * sum(ev)
+
+
 def test_full_size_render_image_native_pass(oracle, full_frame):
     """800x800 (BASELINE config 2): render_image through ced_render_image equals the staged composition in every pixel
     and every per-sample array, and evaluates the field on far fewer samples than the march holds."""

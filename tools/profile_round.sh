@@ -17,6 +17,8 @@ for prec in f32 f16x2; do
   ARGS="$ARGS --no-single-frame"
   timeout -k 10 400 rocprofv3 --kernel-trace --stats -d $OUT/kt_$prec -o kt --output-format csv -- python3 $ARGS > $OUT/${TAG}_${prec}_bench_under_rocprof.json 2> $OUT/kt_$prec.err
   cp $(ls $OUT/kt_$prec/*kernel_stats.csv | head -1) $OUT/${TAG}_${prec}_kernel_stats.csv
+  # the same two figures bench.py reports, from the profiler's own trace (warm-up step's 36 dispatches left out)
+  python3 $R/tools/field_busy_from_trace.py $OUT/kt_$prec 36 > $OUT/${TAG}_${prec}_busy_from_trace.txt
   echo "kernel trace $prec done"
   # 3. HBM bytes: FETCH_SIZE and WRITE_SIZE in separate passes
   timeout -k 10 400 rocprofv3 --pmc FETCH_SIZE -d $OUT/pmc_fetch_$prec -o f --output-format csv -- python3 $ARGS > /dev/null 2> $OUT/pmc_fetch_$prec.err
