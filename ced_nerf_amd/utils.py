@@ -106,7 +106,8 @@ def render_image(
         chunk_rays = namedtuple_map(lambda r: r[i:i + pass_rays].contiguous().float(), rays)
         ts = timestamps[i:i + pass_rays] if training else timestamps
         n_pass = chunk_rays.origins.shape[0]
-        if native:
+        two_pass = native and float(alpha_thre) > 0.0
+        if native and not two_pass:
             t_all0, t_all1, _, packed_all = estimator.march(
                 chunk_rays.origins, chunk_rays.viewdirs, near_plane=near_plane, far_plane=far_plane,
                 render_step_size=render_step_size, stratified=False, cone_angle=cone_angle, want_ray_indices=False)
@@ -141,9 +142,13 @@ def render_image(
             return radiance_field.query_rays(chunk_rays.origins, chunk_rays.viewdirs, ray_indices, t_starts, t_ends,
                                              ts, want_rgb=True)
 
+        # With an alpha threshold most marched samples may be dropped without ending their ray (C3, C4): the native pass
+        # is then the filter alone on the density-only kernel (front to back, rays stopped at the transmittance test)
+        # and the whole field only on the survivors -- `sampling` and `rendering` as the reference stages them.
         ray_indices, t_starts, t_ends = estimator.sampling(
             chunk_rays.origins, chunk_rays.viewdirs, sigma_fn=sigma_fn, near_plane=near_plane, far_plane=far_plane,
-            render_step_size=render_step_size, stratified=training, cone_angle=cone_angle, alpha_thre=alpha_thre)
+            render_step_size=render_step_size, stratified=training, cone_angle=cone_angle, alpha_thre=alpha_thre,
+            sigma_field=(radiance_field, ts, training) if two_pass else None)
         rgb, opacity, depth, extras = rendering(t_starts, t_ends, ray_indices, n_rays=n_pass,
                                                 rgb_sigma_fn=rgb_sigma_fn, render_bkgd=render_bkgd)
         extras["ray_indices"] = ray_indices
@@ -155,17 +160,13 @@ def render_image(
             continue
         # cut the pass into the reference's chunks: samples are sorted by ray, so each chunk owns a
         # contiguous sample range (one small device->host copy of the range boundaries)
-        starts = torch.arange(0, n_pass + test_chunk_size, test_chunk_size, device=rgb.device).clamp_(max=n_pass)
-        bounds = torch.searchsorted(ray_indices, starts).tolist()
-        for c in range(len(bounds) - 1):
-            r0, r1 = c * test_chunk_size, min((c + 1) * test_chunk_size, n_pass)
-            if r0 >= n_pass:
-                break
-            s0, s1 = bounds[c], bounds[c + 1]
-            ex = {k: v[s0:s1] for k, v in extras.items()}
-            ex["ray_indices"] = ex["ray_indices"] - r0
-            results.append([rgb[r0:r1], opacity[r0:r1], depth[r0:r1], s1 - s0])
-            extra_info.append(ex)
+        starts = list(range(0, n_pass, test_chunk_size)) + [n_pass]
+        bounds = torch.searchsorted(ray_indices, torch.tensor(starts, device=rgb.device)).tolist()
+        sizes = [bounds[c + 1] - bounds[c] for c in range(len(starts) - 1)]
+        extras["ray_indices"] = ray_indices % test_chunk_size         # relative to the ray's chunk
+        cut = {k: v.split(sizes) for k, v in extras.items()}
+        results.append([rgb, opacity, depth, len(t_starts)])          # the pixels of a pass stay whole
+        extra_info.extend([{k: cut[k][c] for k in cut} for c in range(len(sizes))])
     colors, opacities, depths, n_rendering_samples = [
         torch.cat(r, dim=0) if isinstance(r[0], torch.Tensor) else r for r in zip(*results)
     ]

@@ -686,6 +686,17 @@ def test_render_image_native_pass_matches_staged_composition(oracle, name, wh, c
     if alpha_thre > 0.0:
         al = torch.cat([e["alphas"] for e in a[4]])
         assert bool((al >= alpha_thre).all())
+        # render_image takes the two-pass form with a threshold; the one-pass kernel handles it too (C-ABI contract)
+        from ced_nerf_amd import ops
+        o = rays.origins.reshape(-1, 3).contiguous(); d = rays.viewdirs.reshape(-1, 3).contiguous()
+        t0, t1, _, packed = est.march(o, d, near_plane=rk["near_plane"], far_plane=rk["far_plane"],
+                                      render_step_size=rk["render_step_size"], cone_angle=rk["cone_angle"])
+        one = ops.render_image_eval_native(f._descriptor(), o, d, packed, t0, t1, 1e-4, alpha_thre, ts.reshape(-1), False,
+                                           rk["render_bkgd"].reshape(-1).float().contiguous())
+        for i in range(3):
+            assert torch.equal(one[i].reshape(b[i].shape), b[i])
+        for k in ("weights", "trans", "alphas", "sigmas", "rgbs", "t_starts", "t_ends"):
+            assert torch.equal(one[3][k], torch.cat([e[k] for e in b[4]])), k
 
 
 def test_render_image_native_pass_empty_and_ragged(oracle):

@@ -8,6 +8,8 @@ files = glob.glob(os.path.join(path, "**", "*kernel_trace.csv"), recursive=True)
 rows = [r for r in csv.DictReader(open(files[0])) if "field_kernel" in r["Kernel_Name"] or "field_half_kernel" in r["Kernel_Name"]]
 iv = sorted((int(r["Start_Timestamp"]), int(r["End_Timestamp"])) for r in rows)
 iv = iv[int(sys.argv[2]) if len(sys.argv) > 2 else 0:]
+n_all = len(iv)
+iv = [(s, e) for s, e in iv if e - s >= 10000]      # launches without work (enqueued ahead of a finished frame) are not launches of the workload
 busy, (cs, ce) = 0, iv[0]
 for s, e in iv[1:]:
     if s > ce:
@@ -15,5 +17,5 @@ for s, e in iv[1:]:
     else:
         ce = max(ce, e)
 busy += ce - cs
-print(f"{len(iv)} dispatches: mean duration {sum(e - s for s, e in iv) / len(iv) / 1e3:.1f} us, "
+print(f"{n_all} dispatches, {len(iv)} with work: mean duration {sum(e - s for s, e in iv) / len(iv) / 1e3:.1f} us, "
       f"field-busy time per dispatch {busy / len(iv) / 1e3:.1f} us, busy / span {busy / (iv[-1][1] - iv[0][0]):.3f}")
