@@ -689,36 +689,43 @@ struct MarchAllArgs {
     AccelSpec accel;
     const float *near_planes;
     float far_plane;
+    const float *t_sorted;         // several grid levels: the rays' sorted entry / exit events (cednerf/utils.py:215-225)
+    const int64_t *t_indices;
+    const uint8_t *hits;
     int64_t *packed;               // [n_rays, 2]: FILL reads the first sample, COUNT writes the count
     float *t_starts, *t_ends;
     int64_t *ray_indices;          // optional
 };
 
-template <bool FILL>
-__global__ __launch_bounds__(kMarchThreads, 4) void march_all_kernel(MarchAllArgs A)
+template <bool SINGLE, bool FILL>
+__global__ __launch_bounds__(kMarchThreads, SINGLE ? 4 : 3) void march_all_kernel(MarchAllArgs A)
 {
     const int64_t r = (int64_t)blockIdx.x * kMarchThreads + threadIdx.x;
     if (r >= A.n_rays) return;
     float o[3], d[3];
 #pragma unroll
     for (int a = 0; a < 3; ++a) { o[a] = A.rays_o[3 * r + a]; d[a] = A.rays_d[3 * r + a]; }
+    const int m = A.grid.n_grids;
+    const float *const ts_row = SINGLE ? nullptr : A.t_sorted + r * 2 * m;
+    const int64_t *const ti_row = SINGLE ? nullptr : A.t_indices + r * 2 * m;
+    const uint8_t *const hit_row = SINGLE ? nullptr : A.hits + r * m;
     float t_term;
     if constexpr (!FILL) {
-        const int n = traverse_ray_frame<kFrameLook, true>(A.grid, A.accel, true, o, d, A.near_planes[r], A.far_plane, nullptr,
-                                                           nullptr, nullptr, [](int, float, float) {}, t_term);
+        const int n = traverse_ray_frame<kFrameLook, SINGLE>(A.grid, A.accel, true, o, d, A.near_planes[r], A.far_plane, ts_row,
+                                                             ti_row, hit_row, [](int, float, float) {}, t_term);
         A.packed[2 * r + 1] = n;
     } else {
         const int64_t start = A.packed[2 * r];
         if (A.packed[2 * r + 1] == 0) return;
         float *const p0 = A.t_starts + start, *const p1 = A.t_ends + start;
         int64_t *const pr = A.ray_indices ? A.ray_indices + start : nullptr;
-        (void)traverse_ray_frame<kFrameLook, true>(A.grid, A.accel, true, o, d, A.near_planes[r], A.far_plane, nullptr, nullptr,
-                                                   nullptr,
-                                                   [&](int i, float t0, float t1) {
-                                                       p0[i] = t0; p1[i] = t1;
-                                                       if (pr) pr[i] = r;
-                                                   },
-                                                   t_term);
+        (void)traverse_ray_frame<kFrameLook, SINGLE>(A.grid, A.accel, true, o, d, A.near_planes[r], A.far_plane, ts_row, ti_row,
+                                                     hit_row,
+                                                     [&](int i, float t0, float t1) {
+                                                         p0[i] = t0; p1[i] = t1;
+                                                         if (pr) pr[i] = r;
+                                                     },
+                                                     t_term);
     }
 }
 
@@ -1247,21 +1254,27 @@ extern "C" int ced_render_image_gather(int64_t n_rays, int64_t n_all, int64_t pr
 
 extern "C" int ced_march_all(int64_t n_rays, const float *rays_o, const float *rays_d, const uint8_t *binaries,
                              int32_t n_grids, int32_t res, const float *aabbs, const void *accel, const float *near_planes,
-                             float far_plane, float step_size, float cone_angle, int32_t fill, int64_t *packed_info,
+                             float far_plane, float step_size, float cone_angle, const float *t_sorted,
+                             const int64_t *t_indices, const uint8_t *hits, int32_t fill, int64_t *packed_info,
                              float *t_starts, float *t_ends, int64_t *ray_indices, void *stream)
 {
-    CED_REQUIRE(n_rays >= 0 && res >= 1 && res <= 1024, "march_all: bad sizes");
-    CED_REQUIRE(n_grids == 1, "march_all: one grid level only (use ced_traverse_grids for %d)", n_grids);
+    CED_REQUIRE(n_rays >= 0 && res >= 1 && res <= 1024 && n_grids >= 1 && n_grids <= ced::kMaxGrids, "march_all: bad sizes");
     if (n_rays == 0) return CED_OK;
     CED_REQUIRE(rays_o && rays_d && binaries && aabbs && accel && near_planes && packed_info, "march_all: null pointer");
+    CED_REQUIRE(n_grids == 1 || (t_sorted && t_indices && hits), "march_all: %d grid levels need the sorted intersections", n_grids);
     CED_REQUIRE(!fill || (t_starts && t_ends), "march_all: fill pass without sample arrays");
     ced::MarchAllArgs A{ n_rays, rays_o, rays_d,
-                         ced::GridSpec{ binaries, aabbs, 1, res, step_size, cone_angle, 0x7fffffff, nullptr },
-                         ced::accel_view(accel, 1, res, true), near_planes, far_plane, packed_info, t_starts, t_ends, ray_indices };
-    const dim3 grid((unsigned)((n_rays + ced::kMarchThreads - 1) / ced::kMarchThreads));
-    if (fill)
-        hipLaunchKernelGGL(ced::march_all_kernel<true>, grid, dim3(ced::kMarchThreads), 0, (hipStream_t)stream, A);
-    else
-        hipLaunchKernelGGL(ced::march_all_kernel<false>, grid, dim3(ced::kMarchThreads), 0, (hipStream_t)stream, A);
+                         ced::GridSpec{ binaries, aabbs, n_grids, res, step_size, cone_angle, 0x7fffffff, nullptr },
+                         ced::accel_view(accel, n_grids, res, true), near_planes, far_plane, t_sorted, t_indices, hits,
+                         packed_info, t_starts, t_ends, ray_indices };
+    const dim3 grid((unsigned)((n_rays + ced::kMarchThreads - 1) / ced::kMarchThreads)), blk(ced::kMarchThreads);
+    hipStream_t st = (hipStream_t)stream;
+    if (n_grids == 1) {
+        if (fill) hipLaunchKernelGGL((ced::march_all_kernel<true, true>), grid, blk, 0, st, A);
+        else hipLaunchKernelGGL((ced::march_all_kernel<true, false>), grid, blk, 0, st, A);
+    } else {
+        if (fill) hipLaunchKernelGGL((ced::march_all_kernel<false, true>), grid, blk, 0, st, A);
+        else hipLaunchKernelGGL((ced::march_all_kernel<false, false>), grid, blk, 0, st, A);
+    }
     return ced::check_launch("march_all");
 }

@@ -338,10 +338,15 @@ class OccGridEstimator(torch.nn.Module):
         if stratified:
             near_planes = near_planes + torch.rand_like(near_planes) * render_step_size
         if fast is None:
-            fast = self.binaries.shape[0] == 1 and t_max is None and rays_o.is_cuda
-        if fast:        # one grid level: the accelerated walk of the frame renderer (same samples, ced_march_all)
+            fast = t_max is None and rays_o.is_cuda
+        if fast:        # the accelerated walk of the frame renderer (same samples, ced_march_all)
+            ev = (None, None, None)
+            if self.binaries.shape[0] > 1:
+                t_mins, t_maxs, hits = ray_aabb_intersect(rays_o, rays_d, self.aabbs)
+                ev = sort_intersections(t_mins, t_maxs) + (hits.contiguous(),)
             return ops.march_all(rays_o, rays_d, self.binaries, self.aabbs, self.occupancy_accel(), near_planes.contiguous(),
-                                 far_plane, render_step_size, cone_angle, want_ray_indices=want_ray_indices)
+                                 far_plane, render_step_size, cone_angle, want_ray_indices=want_ray_indices,
+                                 t_sorted=ev[0], t_indices=ev[1], hits=ev[2])
         t_starts, t_ends, ray_indices, packed_info, _ = march_packed(
             rays_o, rays_d, self.binaries, self.aabbs, near_planes.contiguous(), far_planes.contiguous(),
             render_step_size, cone_angle)

@@ -552,20 +552,24 @@ def render_image_test_native(desc: _lib.FieldDesc, rays_o, rays_d, binaries, aab
 
 
 def march_all(rays_o, rays_d, binaries, aabbs, accel, near_planes, far_plane: float, step_size: float, cone_angle: float,
-              want_ray_indices: bool = True):
-    """ced_march_all: every ray marched to the far plane on the accelerated walk (one grid level).
-    Returns (t_starts, t_ends, ray_indices or None, packed_info [n,2])."""
+              want_ray_indices: bool = True, t_sorted=None, t_indices=None, hits=None):
+    """ced_march_all: every ray marched to the far plane on the accelerated walk.  Several grid levels need the sorted
+    ray / box events (t_sorted, t_indices, hits).  Returns (t_starts, t_ends, ray_indices or None, packed_info [n,2])."""
     _chk(rays_o, torch.float32, "rays_o"); _chk(rays_d, torch.float32, "rays_d")
     _chk(aabbs, torch.float32, "aabbs"); _chk(near_planes, torch.float32, "near_planes")
-    assert binaries.is_cuda and binaries.is_contiguous() and binaries.ndim == 4 and binaries.shape[0] == 1
+    assert binaries.is_cuda and binaries.is_contiguous() and binaries.ndim == 4
     assert accel is not None and accel.is_cuda
     n = rays_o.shape[0]
-    res = binaries.shape[1]
+    m, res = binaries.shape[0], binaries.shape[1]
+    if m > 1:
+        _chk(t_sorted, torch.float32, "t_sorted"); _chk(t_indices, torch.int64, "t_indices")
+        assert t_sorted.shape == (n, 2 * m) and t_indices.shape == (n, 2 * m) and hits.shape == (n, m) and hits.is_contiguous()
     dev = rays_o.device
     L = _lib.lib()
     packed = torch.zeros((n, 2), device=dev, dtype=torch.int64)
-    args = (n, _p(rays_o), _p(rays_d), _p(_as_u8(binaries)), 1, res, _p(aabbs), _p(accel), _p(near_planes), float(far_plane),
-            float(step_size), float(cone_angle))
+    args = (n, _p(rays_o), _p(rays_d), _p(_as_u8(binaries)), m, res, _p(aabbs), _p(accel), _p(near_planes), float(far_plane),
+            float(step_size), float(cone_angle), _p(t_sorted) if m > 1 else None, _p(t_indices) if m > 1 else None,
+            _p(_as_u8(hits)) if m > 1 else None)
     _lib.check(L.ced_march_all(*args, 0, _p(packed), None, None, None, _stream()), "march_all (count)")
     counts = packed[:, 1]
     incl = torch.cumsum(counts, 0)

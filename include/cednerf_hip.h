@@ -468,14 +468,16 @@ int ced_render_image_gather(int64_t n_rays, int64_t n_all, int64_t processed, co
 
 /* One-shot march of every ray to the far plane on the accelerated walk of the frame renderer: the samples of
  * nerfacc.traverse_grids without a step limit (the marching half of OccGridEstimator.sampling, call sites
- * cednerf/utils.py:115-125, train_real.py:339-350), bit for bit, 3x faster than ced_traverse_grids through empty space.
- * One grid level only (n_grids == 1; more: ced_traverse_grids).  accel: ced_build_occupancy_accel's structure.
+ * cednerf/utils.py:115-125, train_real.py:339-350), bit for bit, faster than ced_traverse_grids through empty space.
+ * accel: ced_build_occupancy_accel's structure.  t_sorted [n_rays, 2 n_grids], t_indices (int64), hits [n_rays, n_grids]:
+ * the sorted ray / box events of cednerf/utils.py:215-225 (ced_ray_aabb_intersect + stable sort); NULL for one level.
  * fill = 0: packed_info[r][1] = samples of ray r.  The caller scans the counts into packed_info[r][0].
  * fill = 1: writes t_starts / t_ends (and ray_indices, optional) of ray r from packed_info[r][0] on. */
 int ced_march_all(int64_t n_rays, const float *rays_o, const float *rays_d, const uint8_t *binaries, int32_t n_grids,
                   int32_t res, const float *aabbs, const void *accel, const float *near_planes, float far_plane,
-                  float render_step_size, float cone_angle, int32_t fill, int64_t *packed_info, float *t_starts,
-                  float *t_ends, int64_t *ray_indices, void *stream);
+                  float render_step_size, float cone_angle, const float *t_sorted, const int64_t *t_indices,
+                  const uint8_t *hits, int32_t fill, int64_t *packed_info, float *t_starts, float *t_ends,
+                  int64_t *ray_indices, void *stream);
 
 #ifdef __cplusplus
 }

@@ -699,6 +699,53 @@ def test_render_image_native_pass_matches_staged_composition(oracle, name, wh, c
             assert torch.equal(one[3][k], torch.cat([e[k] for e in b[4]])), k
 
 
+@pytest.mark.parametrize("name,wh", [("hypernerf", (268, 480)), ("dynerf", (338, 254)), ("dnerf", (200, 200))])
+def test_one_shot_march_matches_traverse_grids(oracle, name, wh):
+    """ced_march_all on one, two and four grid levels (cone angle 0 and 0.004), common and stratified near planes,
+    against ced_traverse_grids: packed info and every sample bit for bit."""
+    from ced_nerf_amd.nerfacc_api import OccGridEstimator
+    sc = _scene(name, wh[0], wh[1], "trained", log2_hashmap_size=15)
+    cfg = sc["cfg"]
+    est = OccGridEstimator(cfg["aabb"], cfg["grid_resolution"], cfg["grid_levels"]).to(DEV)
+    est.set_binaries(T(sc["binaries"]))
+    o = T(sc["origins"]).reshape(-1, 3).contiguous(); d = T(sc["viewdirs"]).reshape(-1, 3).contiguous()
+    for stratified in (False, True):
+        kw = dict(near_plane=cfg["near_plane"], far_plane=cfg["far_plane"], render_step_size=cfg["render_step_size"],
+                  cone_angle=cfg["cone_angle"], stratified=stratified)
+        torch.manual_seed(11)
+        a = est.march(o, d, fast=True, **kw)
+        torch.manual_seed(11)
+        b = est.march(o, d, fast=False, **kw)
+        assert b[0].shape[0] > 10000
+        for x, y, nm in zip(a, b, ("t_starts", "t_ends", "ray_indices", "packed_info")):
+            assert x.dtype == y.dtype and torch.equal(x, y), (name, nm, stratified)
+
+
+def test_render_image_several_internal_passes(oracle, monkeypatch):
+    """render_image cuts a large eval frame into internal passes of whole chunks: with the pass size forced down to two
+    chunks the output (pixels, the per-chunk extras list) is that of one pass, on both paths, and equals the oracle's."""
+    from ced_nerf_amd import utils as U
+    sc = _scene("dnerf", 80, 60, "trained", log2_hashmap_size=17)
+    of, oest, f, est, rays, rk = _setup(oracle, sc)
+    ts = T(sc["timestamps"])
+    one = U.render_image(f, est, rays, timestamps=ts, test_chunk_size=1000, native=True, **rk)
+    monkeypatch.setattr(U, "_EVAL_PASS_RAYS", 2000)
+    for native in (True, False):
+        many = U.render_image(f, est, rays, timestamps=ts, test_chunk_size=1000, native=native, **rk)
+        assert many[3] == one[3] and len(many[4]) == len(one[4]) == 5
+        for i in range(3):
+            assert torch.equal(many[i], one[i])
+        for a, b in zip(many[4], one[4]):
+            for k in b:
+                assert torch.equal(a[k], b[k]), (native, k)
+    w = oracle.render_image(of, oest, sc["origins"], sc["viewdirs"], timestamps=sc["timestamps"], test_chunk_size=1000,
+                            **sc["render"])
+    assert one[3] == w[3]
+    for ge, we in zip(one[4], w[4]):
+        assert_bitexact(N(ge["ray_indices"]), we["ray_indices"], "ray_indices")
+        assert_bitexact(N(ge["weights"]), we["weights"], "weights")
+
+
 def test_render_image_native_pass_empty_and_ragged(oracle):
     """Rays that miss the grid (no samples), a pass smaller than a chunk, and zero rays."""
     from ced_nerf_amd.utils import Rays, render_image
