@@ -665,7 +665,9 @@ int launch_field(const ced_field_desc *d, FieldArgs &A, void *stream)
         // the half kernels gather level 4i + g in slot i: the same slot -> level-range mapping as above
         return launch_field_half(A, d->time_mode, d->mlp_precision, stream);
     }
-    const int variant = g_field_variant;
+    // 768 threads (three waves per SIMD, 168 registers) is the default; the time-embedding and temporal-table kernels
+    // spill at that cap (76-380 B per lane) and run two waves per SIMD without scratch instead (C3: +1.8 %)
+    const int variant = (g_field_variant == 2 && (d->time_mode || A.temporal)) ? 1 : g_field_variant;
     auto launch = [&](auto kernel, int nt, int threads) {
         const int64_t n_tiles = (A.n + 16 * nt - 1) / (16 * nt);
         const int waves = threads / 64;
