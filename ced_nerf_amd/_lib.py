@@ -110,7 +110,7 @@ PROTOTYPES = {
                                          C.POINTER(FrameTrace), _vp, _vp]),
     "ced_wall_clock_khz": (_i64, []),
     "ced_march_all": (C.c_int, [_i64, _vp, _vp, _vp, _i32, _i32, _vp, _vp, _vp, _f, _f, _f, _vp, _vp, _vp, _i32, _vp, _vp, _vp,
-                                _vp, _vp]),
+                                _vp, _i64, _vp, _vp]),
     "ced_render_image_workspace_bytes": (_i64, [_i64, _i64]),
     "ced_render_image": (C.c_int, [C.POINTER(FieldDesc), _i64, _vp, _vp, _i64, _vp, _vp, _vp, _f, _f, _vp, _i32, _vp, _vp, _vp,
                                    _vp, _vp, _vp, _i64, _vp, C.POINTER(_i64), _vp, _vp]),

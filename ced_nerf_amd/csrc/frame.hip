@@ -489,8 +489,16 @@ __global__ __launch_bounds__(256) void image_prep_kernel(int64_t n_rays, ImageSt
 
 // The iteration's samples: the next `limit` samples of every alive ray, copied from the one-shot march into the
 // iteration's window of the persistent arrays (ray-packed, one range reservation per workgroup as in march_frame_kernel).
+// samples of ray r in the one-shot march; a range that passes the end of the arrays (a one-pass march that overflowed
+// its capacity: the caller redoes the frame) counts as empty, so that nothing out of bounds is ever read
+__device__ __forceinline__ int64_t ray_count(const int64_t *__restrict__ packed_all, int64_t r, int64_t n_all)
+{
+    const int64_t start = packed_all[2 * r], cnt = packed_all[2 * r + 1];
+    return (start < 0 || cnt < 0 || start + cnt > n_all) ? 0 : cnt;
+}
+
 __global__ __launch_bounds__(kMarchThreads) void image_chunk_kernel(
-    IterPlan *__restrict__ plan, int64_t n_rays, const int32_t *__restrict__ alive, const int64_t *__restrict__ packed_all,
+    IterPlan *__restrict__ plan, int64_t n_all, const int32_t *__restrict__ alive, const int64_t *__restrict__ packed_all,
     const float *__restrict__ t0_all, const float *__restrict__ t1_all, const int32_t *__restrict__ cursor,
     float *__restrict__ t0s, float *__restrict__ t1s, int32_t *__restrict__ ridx, int32_t *__restrict__ packed)
 {
@@ -510,7 +518,7 @@ __global__ __launch_bounds__(kMarchThreads) void image_chunk_kernel(
         int64_t src = 0;
         if (active) {
             const int cur = cursor[r];
-            const int64_t left = packed_all[2 * r + 1] - cur;
+            const int64_t left = ray_count(packed_all, r, n_all) - cur;
             n = (int)(left < limit ? left : limit);
             src = packed_all[2 * r] + cur;
         }
@@ -552,10 +560,11 @@ __global__ __launch_bounds__(kCompositeThreads) void image_composite_kernel(
     const int32_t *__restrict__ packed, const int64_t *__restrict__ packed_all, const float *__restrict__ t0,
     const float *__restrict__ t1, const float *__restrict__ sig, const float *__restrict__ rgbs, ImageState st,
     float *__restrict__ w_out, float *__restrict__ tr_out, float *__restrict__ al_out, int32_t *__restrict__ rank_out,
-    float *__restrict__ rgb, float *__restrict__ opacity, float *__restrict__ depth, float eps, float alpha_thre)
+    float *__restrict__ rgb, float *__restrict__ opacity, float *__restrict__ depth, float eps, float alpha_thre,
+    int64_t n_all)
 {
     constexpr int kWaves = kCompositeThreads / 64;
-    __shared__ int wave_alive[kWaves], wave_samples[kWaves];
+    __shared__ int wave_alive[kWaves], wave_samples[kWaves], wave_kept[kWaves];
     __shared__ long long block_base;
     const IterPlan &P = *plan;
     const int64_t total = P.count[0];
@@ -563,7 +572,7 @@ __global__ __launch_bounds__(kCompositeThreads) void image_composite_kernel(
         const int64_t idx = s0 + threadIdx.x;
         const bool active = idx < total;
         const int64_t r = active ? (alive_list ? (int64_t)alive_list[idx] : idx) : 0;
-        int cnt = 0;
+        int cnt = 0, kept_new = 0;
         bool alive = false;
         if (active) {
             const int64_t sb = packed[2 * r];
@@ -573,6 +582,7 @@ __global__ __launch_bounds__(kCompositeThreads) void image_composite_kernel(
                 if constexpr (FULL) { c0 = rgb[3 * r]; c1 = rgb[3 * r + 1]; c2 = rgb[3 * r + 2]; op = opacity[r]; dp = depth[r]; }
                 float acc = st.acc_all[r], acck = st.acc_kept[r];
                 int kept = st.kept[r];
+                const int kept_before = kept;
                 bool open = true;                   // false once a sample failed the transmittance test: the rest fail too
                 constexpr int kU = 4;
                 const int64_t end = sb + cnt;
@@ -619,22 +629,26 @@ __global__ __launch_bounds__(kCompositeThreads) void image_composite_kernel(
                 const int cur = st.cursor[r] + cnt;
                 st.cursor[r] = cur;
                 st.acc_all[r] = acc; st.acc_kept[r] = acck; st.kept[r] = kept;
+                kept_new = kept - kept_before;
                 // alive: samples left, and the next one would pass the transmittance test
-                alive = open && (int64_t)cur < packed_all[2 * r + 1] && (det_expf(-acc) >= eps);
+                alive = open && (int64_t)cur < ray_count(packed_all, r, n_all) && (det_expf(-acc) >= eps);
             }
         }
         const unsigned long long ballot = __ballot(alive);
         const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-        int wsum = cnt;
+        int wsum = cnt, ksum = kept_new;
 #pragma unroll
-        for (int off = 32; off >= 1; off >>= 1) wsum += __shfl_xor(wsum, off, 64);
-        if (lane == 0) { wave_alive[wave] = __builtin_popcountll(ballot); wave_samples[wave] = wsum; }
+        for (int off = 32; off >= 1; off >>= 1) { wsum += __shfl_xor(wsum, off, 64); ksum += __shfl_xor(ksum, off, 64); }
+        if (lane == 0) { wave_alive[wave] = __builtin_popcountll(ballot); wave_samples[wave] = wsum; wave_kept[wave] = ksum; }
         __syncthreads();
         if (threadIdx.x == 0) {
-            int run = 0, samples = 0;
-            for (int w = 0; w < kWaves; ++w) { int t = wave_alive[w]; wave_alive[w] = run; run += t; samples += wave_samples[w]; }
+            int run = 0, samples = 0, keptw = 0;
+            for (int w = 0; w < kWaves; ++w) {
+                int t = wave_alive[w]; wave_alive[w] = run; run += t; samples += wave_samples[w]; keptw += wave_kept[w];
+            }
             const unsigned long long add = (unsigned long long)run + ((unsigned long long)samples << 32);
             block_base = add != 0 ? (long long)(atomicAdd(&plan->next[0], add) & 0xffffffffull) : 0;
+            if (keptw) atomicAdd(&plan->next[1], (unsigned long long)keptw);       // kept samples of the iteration
         }
         __syncthreads();
         if (alive) {
@@ -726,6 +740,91 @@ __global__ __launch_bounds__(kMarchThreads, SINGLE ? 4 : 3) void march_all_kerne
                                                          if (pr) pr[i] = r;
                                                      },
                                                      t_term);
+    }
+}
+
+// The same march in ONE pass, for callers that can bound the total (a video's frames: the previous frame's count):
+// every lane walks once remembering its samples as runs (as march_frame_kernel does), the workgroup reserves one
+// range of the caller's arrays from a device counter and the samples are regenerated there.  Rays land in workgroup
+// arrival order (packed_info says where); a ray whose range would pass `capacity` stores nothing -- the counter then
+// exceeds the capacity and the caller falls back to the two-pass form.
+template <bool SINGLE>
+__global__ __launch_bounds__(kMarchThreads, SINGLE ? 4 : 3) void march_all_onepass_kernel(MarchAllArgs A, int64_t capacity,
+                                                                                         unsigned long long *total)
+{
+    constexpr int kWaves = kMarchThreads / 64;
+    __shared__ int wave_tot[kWaves];
+    __shared__ long long block_base;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int64_t r = (int64_t)blockIdx.x * kMarchThreads + threadIdx.x;
+    const bool active = r < A.n_rays;
+    const int m = A.grid.n_grids;
+    float o[3] = { 0.0f, 0.0f, 0.0f }, d[3] = { 0.0f, 0.0f, 1.0f };
+    float near = 0.0f, t_term = 0.0f;
+    float run_t[kMaxRuns];
+    int run_n[kMaxRuns];
+#pragma unroll
+    for (int k = 0; k < kMaxRuns; ++k) { run_t[k] = 0.0f; run_n[k] = 0; }
+    int n = 0, n_runs = 0;
+    const float *const ts_row = (SINGLE || !active) ? nullptr : A.t_sorted + r * 2 * m;
+    const int64_t *const ti_row = (SINGLE || !active) ? nullptr : A.t_indices + r * 2 * m;
+    const uint8_t *const hit_row = (SINGLE || !active) ? nullptr : A.hits + r * m;
+    if (active) {
+#pragma unroll
+        for (int a = 0; a < 3; ++a) { o[a] = A.rays_o[3 * r + a]; d[a] = A.rays_d[3 * r + a]; }
+        near = A.near_planes[r];
+        float prev_end = 0.0f;
+        n = traverse_ray_frame<kFrameLook, SINGLE>(
+            A.grid, A.accel, true, o, d, near, A.far_plane, ts_row, ti_row, hit_row,
+            [&](int i, float t0, float t1) {
+                const bool fresh = i == 0 || t0 != prev_end;
+                if (fresh) ++n_runs;
+                prev_end = t1;
+#pragma unroll
+                for (int k = 0; k < kMaxRuns; ++k) {
+                    const bool here = n_runs == k + 1;
+                    run_t[k] = (here && fresh) ? t0 : run_t[k];
+                    run_n[k] += here ? 1 : 0;
+                }
+            },
+            t_term);
+    }
+    int incl = n;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+        const int v = __shfl_up(incl, off, 64);
+        if (lane >= off) incl += v;
+    }
+    if (lane == 63) wave_tot[wave] = incl;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        int run = 0;
+        for (int w = 0; w < kWaves; ++w) { const int t = wave_tot[w]; wave_tot[w] = run; run += t; }
+        block_base = run > 0 ? (long long)atomicAdd(total, (unsigned long long)run) : 0;
+    }
+    __syncthreads();
+    if (!active) return;
+    const int64_t start = (int64_t)block_base + wave_tot[wave] + (incl - n);
+    A.packed[2 * r] = start;
+    A.packed[2 * r + 1] = n;
+    if (n == 0 || start + n > capacity) return;
+    float *const p0 = A.t_starts + start, *const p1 = A.t_ends + start;
+    if (n_runs > kMaxRuns || !(A.grid.step_size > 0.0f)) {
+        float unused;
+        (void)traverse_ray_frame<kFrameLook, SINGLE>(A.grid, A.accel, true, o, d, near, A.far_plane, ts_row, ti_row, hit_row,
+                                                     [&](int i, float t0, float t1) { p0[i] = t0; p1[i] = t1; }, unused);
+    } else {
+        int pos = 0;
+#pragma unroll
+        for (int k = 0; k < kMaxRuns; ++k) {
+            float t = run_t[k];
+            for (int j = 0; j < run_n[k]; ++j) {
+                const float t1 = t + calc_dt(t, A.grid.cone_angle, A.grid.step_size, 1e10f);
+                p0[pos] = t; p1[pos] = t1;
+                ++pos;
+                t = t1;
+            }
+        }
     }
 }
 
@@ -1102,7 +1201,7 @@ static int render_image_impl(const ced_field_desc *field, int64_t n_rays, const 
         int64_t mgrid = (alive_bound + kMarchThreads - 1) / kMarchThreads;
         if (mgrid > 8192) mgrid = 8192;
         if (mgrid < 1) mgrid = 1;
-        hipLaunchKernelGGL(image_chunk_kernel, dim3((unsigned)mgrid), dim3(kMarchThreads), 0, stream, plan, n_rays, cur_list,
+        hipLaunchKernelGGL(image_chunk_kernel, dim3((unsigned)mgrid), dim3(kMarchThreads), 0, stream, plan, n_all, cur_list,
                            packed_all, t0_all, t1_all, W.st.cursor, W.t0, W.t1, W.ridx, W.packed);
         FieldArgs F{};
         F.n = n_rays;                       // an iteration's samples: alive * N_samples <= n_rays; exact count from the plan
@@ -1123,12 +1222,12 @@ static int render_image_impl(const ced_field_desc *field, int64_t n_rays, const 
         if (full)
             hipLaunchKernelGGL(image_composite_kernel<true>, dim3((unsigned)cgrid), dim3(kCompositeThreads), 0, stream, plan,
                                cur_list, next_list, W.packed, packed_all, W.t0, W.t1, W.sigma, W.rgbs, W.st, W.w, W.tr, W.al,
-                               W.rank, rgb, opacity, depth, early_stop_eps, alpha_thre);
+                               W.rank, rgb, opacity, depth, early_stop_eps, alpha_thre, n_all);
         else
             hipLaunchKernelGGL(image_composite_kernel<false>, dim3((unsigned)cgrid), dim3(kCompositeThreads), 0, stream, plan,
                                cur_list, next_list, W.packed, packed_all, W.t0, W.t1, W.sigma, (const float *)nullptr, W.st,
                                (float *)nullptr, (float *)nullptr, (float *)nullptr, W.rank, (float *)nullptr,
-                               (float *)nullptr, (float *)nullptr, early_stop_eps, alpha_thre);
+                               (float *)nullptr, (float *)nullptr, early_stop_eps, alpha_thre, n_all);
         hipLaunchKernelGGL(frame_schedule_kernel, dim3(1), dim3(64), 0, stream,
                            ScheduleArgs{ W.plans, it, 1, (int)n_rays, 1, big, (long long *)host_stats, seq });
         rc = check_launch("render_image (iteration)");
@@ -1142,12 +1241,13 @@ static int render_image_impl(const ced_field_desc *field, int64_t n_rays, const 
     if (hipMemcpyAsync(plans.data(), W.plans, plans.size() * sizeof(IterPlan), hipMemcpyDeviceToHost, stream) != hipSuccess ||
         hipStreamSynchronize(stream) != hipSuccess)
         return check_launch("render_image (read-back)");
-    int64_t processed = 0;
+    int64_t processed = 0, kept_total = 0;
     int n_iters = 0;
     for (int k = 0; k < enqueued; ++k) {
         const IterPlan &P = plans[k];
         if (P.done || P.count[0] == 0) break;
         processed = P.sample_base + P.total_samples;
+        kept_total += (int64_t)P.next[1];
         ++n_iters;
     }
     if (n_iters == enqueued && enqueued == kImageMaxIters && !plans[enqueued].done) {
@@ -1155,7 +1255,7 @@ static int render_image_impl(const ced_field_desc *field, int64_t n_rays, const 
         return CED_E_LAUNCH;
     }
     CED_REQUIRE(processed <= cap, "%s: internal: %lld samples processed, capacity %lld", who, (long long)processed, (long long)cap);
-    if (stats_out) { stats_out[0] = processed; stats_out[1] = n_iters; }
+    if (stats_out) { stats_out[0] = processed; stats_out[1] = n_iters; stats_out[2] = kept_total; }
     return CED_OK;
 }
 
@@ -1256,7 +1356,8 @@ extern "C" int ced_march_all(int64_t n_rays, const float *rays_o, const float *r
                              int32_t n_grids, int32_t res, const float *aabbs, const void *accel, const float *near_planes,
                              float far_plane, float step_size, float cone_angle, const float *t_sorted,
                              const int64_t *t_indices, const uint8_t *hits, int32_t fill, int64_t *packed_info,
-                             float *t_starts, float *t_ends, int64_t *ray_indices, void *stream)
+                             float *t_starts, float *t_ends, int64_t *ray_indices, int64_t capacity, int64_t *total,
+                             void *stream)
 {
     CED_REQUIRE(n_rays >= 0 && res >= 1 && res <= 1024 && n_grids >= 1 && n_grids <= ced::kMaxGrids, "march_all: bad sizes");
     if (n_rays == 0) return CED_OK;
@@ -1269,6 +1370,16 @@ extern "C" int ced_march_all(int64_t n_rays, const float *rays_o, const float *r
                          packed_info, t_starts, t_ends, ray_indices };
     const dim3 grid((unsigned)((n_rays + ced::kMarchThreads - 1) / ced::kMarchThreads)), blk(ced::kMarchThreads);
     hipStream_t st = (hipStream_t)stream;
+    if (fill == 2) {
+        CED_REQUIRE(capacity >= 0 && total != nullptr, "march_all: the one-pass form needs a capacity and a device counter");
+        if (n_grids == 1)
+            hipLaunchKernelGGL((ced::march_all_onepass_kernel<true>), grid, blk, 0, st, A, capacity,
+                               reinterpret_cast<unsigned long long *>(total));
+        else
+            hipLaunchKernelGGL((ced::march_all_onepass_kernel<false>), grid, blk, 0, st, A, capacity,
+                               reinterpret_cast<unsigned long long *>(total));
+        return ced::check_launch("march_all (one pass)");
+    }
     if (n_grids == 1) {
         if (fill) hipLaunchKernelGGL((ced::march_all_kernel<true, true>), grid, blk, 0, st, A);
         else hipLaunchKernelGGL((ced::march_all_kernel<true, false>), grid, blk, 0, st, A);

@@ -352,6 +352,20 @@ class OccGridEstimator(torch.nn.Module):
             render_step_size, cone_angle)
         return t_starts, t_ends, ray_indices, packed_info
 
+    def march_onepass(self, rays_o, rays_d, near_plane: float, far_plane: float, render_step_size: float,
+                      cone_angle: float, capacity: int):
+        """`march` in one pass into arrays of `capacity` samples (ops.march_all_onepass): for a caller that can bound the
+        total, e.g. by the previous frame's.  Returns (t_starts, t_ends, packed_info, total [device int64])."""
+        rays_o = rays_o.contiguous(); rays_d = rays_d.contiguous()
+        near_planes = torch.full_like(rays_o[..., 0], fill_value=near_plane)
+        ev = (None, None, None)
+        if self.binaries.shape[0] > 1:
+            t_mins, t_maxs, hits = ray_aabb_intersect(rays_o, rays_d, self.aabbs)
+            ev = sort_intersections(t_mins, t_maxs) + (hits.contiguous(),)
+        return ops.march_all_onepass(rays_o, rays_d, self.binaries, self.aabbs, self.occupancy_accel(), near_planes,
+                                     far_plane, render_step_size, cone_angle, capacity, t_sorted=ev[0], t_indices=ev[1],
+                                     hits=ev[2])
+
     def sampling(self, rays_o, rays_d, sigma_fn: Optional[Callable] = None, alpha_fn: Optional[Callable] = None,
                  near_plane: float = 0.0, far_plane: float = 1e10, t_min=None, t_max=None,
                  render_step_size: float = 1e-3, early_stop_eps: float = 1e-4, alpha_thre: float = 0.0,

@@ -570,7 +570,7 @@ def march_all(rays_o, rays_d, binaries, aabbs, accel, near_planes, far_plane: fl
     args = (n, _p(rays_o), _p(rays_d), _p(_as_u8(binaries)), m, res, _p(aabbs), _p(accel), _p(near_planes), float(far_plane),
             float(step_size), float(cone_angle), _p(t_sorted) if m > 1 else None, _p(t_indices) if m > 1 else None,
             _p(_as_u8(hits)) if m > 1 else None)
-    _lib.check(L.ced_march_all(*args, 0, _p(packed), None, None, None, _stream()), "march_all (count)")
+    _lib.check(L.ced_march_all(*args, 0, _p(packed), None, None, None, 0, None, _stream()), "march_all (count)")
     counts = packed[:, 1]
     incl = torch.cumsum(counts, 0)
     packed[:, 0] = incl - counts
@@ -579,8 +579,36 @@ def march_all(rays_o, rays_d, binaries, aabbs, accel, near_planes, far_plane: fl
     t_ends = torch.empty((total,), device=dev, dtype=torch.float32)
     ray_indices = torch.empty((total,), device=dev, dtype=torch.int64) if want_ray_indices else None
     if total > 0:
-        _lib.check(L.ced_march_all(*args, 1, _p(packed), _p(t_starts), _p(t_ends), _p(ray_indices), _stream()), "march_all (fill)")
+        _lib.check(L.ced_march_all(*args, 1, _p(packed), _p(t_starts), _p(t_ends), _p(ray_indices), 0, None, _stream()),
+                   "march_all (fill)")
     return t_starts, t_ends, ray_indices, packed
+
+
+def march_all_onepass(rays_o, rays_d, binaries, aabbs, accel, near_planes, far_plane: float, step_size: float,
+                      cone_angle: float, capacity: int, t_sorted=None, t_indices=None, hits=None):
+    """ced_march_all, one pass (fill = 2) into arrays of `capacity` samples.  Returns (t_starts, t_ends, packed_info,
+    total) with `total` a DEVICE int64 scalar: the samples marched; > capacity means some rays stored nothing.  Rays'
+    ranges are in workgroup arrival order (not sorted by ray)."""
+    _chk(rays_o, torch.float32, "rays_o"); _chk(rays_d, torch.float32, "rays_d")
+    _chk(aabbs, torch.float32, "aabbs"); _chk(near_planes, torch.float32, "near_planes")
+    assert binaries.is_cuda and binaries.is_contiguous() and binaries.ndim == 4 and accel is not None and accel.is_cuda
+    n = rays_o.shape[0]
+    m, res = binaries.shape[0], binaries.shape[1]
+    if m > 1:
+        _chk(t_sorted, torch.float32, "t_sorted"); _chk(t_indices, torch.int64, "t_indices")
+        assert t_sorted.shape == (n, 2 * m) and t_indices.shape == (n, 2 * m) and hits.shape == (n, m) and hits.is_contiguous()
+    dev = rays_o.device
+    packed = torch.empty((n, 2), device=dev, dtype=torch.int64)
+    total = torch.zeros((1,), device=dev, dtype=torch.int64)
+    t_starts = torch.empty((capacity,), device=dev, dtype=torch.float32)
+    t_ends = torch.empty((capacity,), device=dev, dtype=torch.float32)
+    rc = _lib.lib().ced_march_all(n, _p(rays_o), _p(rays_d), _p(_as_u8(binaries)), m, res, _p(aabbs), _p(accel),
+                                  _p(near_planes), float(far_plane), float(step_size), float(cone_angle),
+                                  _p(t_sorted) if m > 1 else None, _p(t_indices) if m > 1 else None,
+                                  _p(_as_u8(hits)) if m > 1 else None, 2, _p(packed), _p(t_starts), _p(t_ends), None,
+                                  int(capacity), _p(total), _stream())
+    _lib.check(rc, "march_all (one pass)")
+    return t_starts, t_ends, packed, total
 
 
 _image_ws: Dict[tuple, tuple] = {}
@@ -628,7 +656,7 @@ def render_image_eval_native(desc: _lib.FieldDesc, rays_o, rays_d, packed_info, 
     processed = int(stats[0])
     offsets = torch.zeros((n + 1,), device=dev, dtype=torch.int64)
     torch.cumsum(kept, 0, out=offsets[1:])
-    total = int(offsets[-1].item()) if n > 0 else 0
+    total = int(stats[2])                    # = offsets[-1], without another device round trip
     f = lambda *shape: torch.empty(shape, device=dev, dtype=torch.float32)
     extras = {"ray_indices": torch.empty((total,), device=dev, dtype=torch.int64), "t_starts": f(total), "t_ends": f(total),
               "sigmas": f(total), "rgbs": f(total, 3), "weights": f(total), "trans": f(total), "alphas": f(total)}

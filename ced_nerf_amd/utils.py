@@ -51,6 +51,7 @@ trunc_exp = _TruncExp.apply
 
 
 _EVAL_PASS_RAYS = 1 << 21     # rays per internal eval pass of render_image
+_EXACT_MARCH_ONLY = False     # True: render_image never uses the one-pass march with a capacity from the previous frame
 
 
 def _flatten_rays(rays: Rays):
@@ -108,18 +109,38 @@ def render_image(
         n_pass = chunk_rays.origins.shape[0]
         two_pass = native and float(alpha_thre) > 0.0
         if native and not two_pass:
-            t_all0, t_all1, _, packed_all = estimator.march(
-                chunk_rays.origins, chunk_rays.viewdirs, near_plane=near_plane, far_plane=far_plane,
-                render_step_size=render_step_size, stratified=False, cone_angle=cone_angle, want_ray_indices=False)
-            thre = float(alpha_thre)
-            if thre > 0.0:                                      # nerfacc: alpha_thre = min(alpha_thre, occs.mean())
-                thre = min(thre, estimator.occs.mean().item())
             bk = None if render_bkgd is None else render_bkgd.to(chunk_rays.origins.device, torch.float32).reshape(-1).contiguous()
             chunked = n_pass > test_chunk_size
-            rgb, opacity, depth, ex, offsets, _ = ops.render_image_eval_native(
-                radiance_field._descriptor(), chunk_rays.origins, chunk_rays.viewdirs, packed_all, t_all0, t_all1,
-                1e-4, thre, ts.reshape(-1).float().contiguous(), False, bk,
-                chunk_rays=test_chunk_size if chunked else 0)
+            tq = ts.reshape(-1).float().contiguous()
+
+            def run(t_all0, t_all1, packed_all):
+                return ops.render_image_eval_native(radiance_field._descriptor(), chunk_rays.origins, chunk_rays.viewdirs,
+                                                    packed_all, t_all0, t_all1, 1e-4, 0.0, tq, False, bk,
+                                                    chunk_rays=test_chunk_size if chunked else 0)
+
+            # The march of every ray to the far plane needs the sample total before it can store (count pass, scan, fill
+            # pass).  Consecutive frames of a video march about the same number of samples, so once a pass of this size
+            # has been rendered the march runs in ONE pass into arrays 25 % larger than the last total; should a frame
+            # not fit (the device-side total says so after the render) it is redone with the exact two-pass march.
+            hints = estimator.__dict__.setdefault("_march_totals", {})
+            hint = hints.get(n_pass)
+            out = None
+            if hint is not None and not _EXACT_MARCH_ONLY:
+                cap = int(hint * 1.25) + 65536
+                t_all0, t_all1, packed_all, total_dev = estimator.march_onepass(
+                    chunk_rays.origins, chunk_rays.viewdirs, near_plane, far_plane, render_step_size, cone_angle, cap)
+                out = run(t_all0, t_all1, packed_all)
+                total = int(total_dev.item())
+                hints[n_pass] = total
+                if total > cap:
+                    out = None
+            if out is None:
+                t_all0, t_all1, _, packed_all = estimator.march(
+                    chunk_rays.origins, chunk_rays.viewdirs, near_plane=near_plane, far_plane=far_plane,
+                    render_step_size=render_step_size, stratified=False, cone_angle=cone_angle, want_ray_indices=False)
+                hints[n_pass] = int(t_all0.shape[0])
+                out = run(t_all0, t_all1, packed_all)
+            rgb, opacity, depth, ex, offsets, _ = out
             extras = {k: ex[k] for k in ("weights", "alphas", "trans", "sigmas", "rgbs", "ray_indices", "t_starts", "t_ends")}
             # a pass's pixels stay whole (cutting them into chunks only to concatenate them again would be ~250 slice
             # calls); the per-chunk `extras` are views cut by one split() per array

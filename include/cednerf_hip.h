@@ -444,7 +444,7 @@ int ced_render_frames_test(const ced_field_desc *field, int32_t n_frames, int64_
  * as ced_traverse_grids produces them (samples sorted by ray).  timestamps as in ced_field_forward_rays.
  * Outputs per ray: rgb [n_rays, 3], opacity, depth (finalised as cednerf/render.py:158-176: background blend, depth /
  * max(opacity, eps)), kept [n_rays] = kept samples of the ray.  stats_out (host int64 [3]): [0] samples evaluated
- * (entries of the workspace's sample arrays), [1] iterations.  host_stats: PINNED host memory, >= 64 bytes (the
+ * (entries of the workspace's sample arrays), [1] iterations, [2] kept samples (= sum of `kept`).  host_stats: PINNED host memory, >= 64 bytes (the
  * iteration schedule is computed on the device and published there, as in ced_render_image_test).  The call returns
  * after one stream synchronisation (the sample total is needed to size the outputs of the gather).
  * ced_render_image_gather then writes the per-sample `extras` of the kept samples in the reference's order (by ray,
@@ -472,12 +472,17 @@ int ced_render_image_gather(int64_t n_rays, int64_t n_all, int64_t processed, co
  * accel: ced_build_occupancy_accel's structure.  t_sorted [n_rays, 2 n_grids], t_indices (int64), hits [n_rays, n_grids]:
  * the sorted ray / box events of cednerf/utils.py:215-225 (ced_ray_aabb_intersect + stable sort); NULL for one level.
  * fill = 0: packed_info[r][1] = samples of ray r.  The caller scans the counts into packed_info[r][0].
- * fill = 1: writes t_starts / t_ends (and ray_indices, optional) of ray r from packed_info[r][0] on. */
+ * fill = 1: writes t_starts / t_ends (and ray_indices, optional) of ray r from packed_info[r][0] on.
+ * fill = 2: ONE pass for callers that can bound the total: `total` (device int64, zero on entry) counts the samples,
+ *   every ray gets a range [packed_info[r][0], + packed_info[r][1]) of t_starts / t_ends [capacity] in workgroup
+ *   arrival order (NOT sorted by ray; ray_indices unused) and stores its samples there if the range ends within
+ *   `capacity`; *total > capacity afterwards means some rays stored nothing (redo with the two-pass form).
+ *   ced_render_image accepts such a march (it treats a range beyond n_all as empty and never reads past the arrays). */
 int ced_march_all(int64_t n_rays, const float *rays_o, const float *rays_d, const uint8_t *binaries, int32_t n_grids,
                   int32_t res, const float *aabbs, const void *accel, const float *near_planes, float far_plane,
                   float render_step_size, float cone_angle, const float *t_sorted, const int64_t *t_indices,
                   const uint8_t *hits, int32_t fill, int64_t *packed_info, float *t_starts, float *t_ends,
-                  int64_t *ray_indices, void *stream);
+                  int64_t *ray_indices, int64_t capacity, int64_t *total, void *stream);
 
 #ifdef __cplusplus
 }

@@ -721,6 +721,47 @@ def test_one_shot_march_matches_traverse_grids(oracle, name, wh):
             assert x.dtype == y.dtype and torch.equal(x, y), (name, nm, stratified)
 
 
+@pytest.mark.parametrize("name,wh", [("dnerf", (200, 200)), ("dynerf", (169, 127))])
+def test_render_image_one_pass_march_and_its_fallback(oracle, name, wh):
+    """The second eval render_image of a given size marches in ONE pass into arrays sized by the previous total (rays in
+    workgroup arrival order); a frame that does not fit is redone with the exact march.  Same arrays every time."""
+    from ced_nerf_amd import ops
+    from ced_nerf_amd.utils import render_image
+    sc = _scene(name, wh[0], wh[1], "trained", log2_hashmap_size=15)
+    of, oest, f, est, rays, rk = _setup(oracle, sc)
+    rk = dict(rk); rk["alpha_thre"] = 0.0
+    ts = T(sc["timestamps"])
+    n = wh[0] * wh[1]
+    first = render_image(f, est, rays, timestamps=ts, native=True, **rk)
+    total = est._march_totals[n]
+    assert total > 100000
+    second = render_image(f, est, rays, timestamps=ts, native=True, **rk)               # one pass, capacity 1.25 x total
+    est._march_totals[n] = 10                                                            # capacity far too small
+    third = render_image(f, est, rays, timestamps=ts, native=True, **rk)                # overflow -> exact march
+    assert est._march_totals[n] == total
+    staged = render_image(f, est, rays, timestamps=ts, native=False, **rk)
+    for other in (second, third, staged):
+        assert other[3] == first[3] and len(other[4]) == len(first[4])
+        for i in range(3):
+            assert torch.equal(other[i], first[i])
+        for a, b in zip(other[4], first[4]):
+            for k in b:
+                assert torch.equal(a[k], b[k]), k
+    # the one-pass march itself: per-ray sample sets equal to the two-pass march's, ranges disjoint and within the total
+    o = rays.origins.reshape(-1, 3).contiguous(); d = rays.viewdirs.reshape(-1, 3).contiguous()
+    t0, t1, packed, tot = est.march_onepass(o, d, rk["near_plane"], rk["far_plane"], rk["render_step_size"],
+                                            rk["cone_angle"], total + 1000)
+    e0, e1, _, epacked = est.march(o, d, near_plane=rk["near_plane"], far_plane=rk["far_plane"],
+                                   render_step_size=rk["render_step_size"], cone_angle=rk["cone_angle"])
+    assert int(tot.item()) == total == e0.shape[0] and torch.equal(packed[:, 1], epacked[:, 1])
+    order = torch.argsort(packed[:, 0] + (packed[:, 1] == 0) * (1 << 40))
+    st, ct = packed[order, 0], packed[order, 1]
+    nz = ct > 0
+    assert bool((st[nz][1:] == (st[nz] + ct[nz])[:-1]).all()) and int(st[nz][0]) == 0
+    idx = torch.repeat_interleave(packed[:, 0], epacked[:, 1]) + (torch.arange(total, device=DEV) - torch.repeat_interleave(epacked[:, 0], epacked[:, 1]))
+    assert torch.equal(t0[idx], e0) and torch.equal(t1[idx], e1)
+
+
 def test_render_image_several_internal_passes(oracle, monkeypatch):
     """render_image cuts a large eval frame into internal passes of whole chunks: with the pass size forced down to two
     chunks the output (pixels, the per-chunk extras list) is that of one pass, on both paths, and equals the oracle's."""
