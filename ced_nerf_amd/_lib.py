@@ -14,7 +14,7 @@ _PKG = os.path.dirname(os.path.abspath(__file__))
 _ROOT = os.path.dirname(_PKG)
 LIB_PATH = os.environ.get("CED_NERF_LIB", os.path.join(_PKG, "libcednerf_hip.so"))
 SOURCES = ["runtime.hip", "march.hip", "composite.hip", "field.hip", "field_half.hip", "frame.hip", "occgrid.hip",
-           "raygen.hip", "wgrad.hip", "pixels.hip", "accel.hip", "linear.hip"]
+           "raygen.hip", "wgrad.hip", "pixels.hip", "accel.hip", "linear.hip", "mlp.hip"]
 MLP_F32, MLP_F16X2, MLP_F16 = 0, 1, 2          # ced_field_desc.mlp_precision
 MLP_PRECISIONS = {"f32": MLP_F32, "f16x2": MLP_F16X2, "f16": MLP_F16}
 # -fno-slp-vectorize: the SLP vectoriser forms packed-fp32 instructions with an op_sel swizzle (v_pk_mul_f32 ...
@@ -109,6 +109,7 @@ PROTOTYPES = {
                                          _f, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _vp, C.POINTER(_i64),
                                          C.POINTER(FrameTrace), _vp, _vp]),
     "ced_wall_clock_khz": (_i64, []),
+    "ced_mlp_chain": (C.c_int, [_i64, _i32, _i32, _vp, C.POINTER(_i32), C.POINTER(_vp), C.POINTER(_vp), C.POINTER(_vp), _i32, _vp]),
     "ced_march_all": (C.c_int, [_i64, _vp, _vp, _vp, _i32, _i32, _vp, _vp, _vp, _f, _f, _f, _vp, _vp, _vp, _i32, _vp, _vp, _vp,
                                 _vp, _i64, _vp, _vp]),
     "ced_render_image_workspace_bytes": (_i64, [_i64, _i64]),

@@ -356,6 +356,39 @@ def linear(x, w, transpose_w: bool = False, relu: bool = False, mask=None):
     return y
 
 
+def mlp_chain(x, weights, backward: bool = False, masks=None, want=None, relu_last: bool = False):
+    """ced_mlp_chain.  Forward: x [n, K0], weights [W_1 .. W_L] (W_l [N_l, N_{l-1}]) -> [a_1 .. a_L] (ReLU on all but the
+    last).  Backward: x = dy [n, N_L], masks[l] = the forward input of layer l (None for no mask), want[l] = whether the
+    gradient with respect to layer l's input is to be stored -> [g_0 .. g_{L-1}] (None where not wanted)."""
+    _chk(x, torch.float32, "x")
+    L = len(weights)
+    assert x.dim() == 2 and 1 <= L <= 6
+    for w in weights:
+        _chk(w, torch.float32, "w")
+    widths = [weights[0].shape[1]] + [w.shape[0] for w in weights]
+    for l in range(1, L):
+        assert weights[l].shape[1] == widths[l], "mlp_chain: layer widths do not chain"
+    n = x.shape[0]
+    dev = x.device
+    if not backward:
+        assert x.shape[1] == widths[0]
+        outs = [torch.empty((n, widths[l + 1]), device=dev, dtype=torch.float32) for l in range(L)]
+        mk = [None] * L
+    else:
+        assert x.shape[1] == widths[L]
+        want = [True] * L if want is None else list(want)
+        outs = [torch.empty((n, widths[l]), device=dev, dtype=torch.float32) if want[l] else None for l in range(L)]
+        mk = [None] * L if masks is None else list(masks)
+        for l in range(L):
+            _chk(mk[l], torch.float32, "mask", allow_none=True)
+            assert mk[l] is None or mk[l].shape == (n, widths[l])
+    vp = lambda ts: (C.c_void_p * L)(*[(t.data_ptr() if t is not None and t.numel() > 0 else None) for t in ts])
+    rc = _lib.lib().ced_mlp_chain(n, L, int(bool(backward)), _p(x), (C.c_int32 * (L + 1))(*widths), vp(weights), vp(outs),
+                                  vp(mk), int(bool(relu_last)), _stream())
+    _lib.check(rc, "mlp_chain")
+    return outs
+
+
 def weight_grad(x, dy):
     """ced_weight_grad: dW [n_out, n_in] = dy^T x over the sample stream (x [S, n_in], dy [S, n_out], fp32)."""
     _chk(x, torch.float32, "x"); _chk(dy, torch.float32, "dy")

@@ -55,14 +55,20 @@ class _MlpFn(torch.autograd.Function):
     through ced_linear with the ReLU derivative fused.  No library GEMM (tcnn FullyFusedMLP forward/backward,
     cednerf/model.py:200-222,280-344)."""
 
+    fused = True          # one launch per direction (ced_mlp_chain); False: layer by layer (ced_linear), same bits
+
     @staticmethod
     def forward(ctx, x, *weights):
         h = x.detach().float().contiguous()
         acts = [h]
         ws = [w.detach().float().contiguous() for w in weights]
-        for i, w in enumerate(ws):
-            h = ops.linear(h, w, relu=i < len(ws) - 1)
-            acts.append(h)
+        if _MlpFn.fused and h.shape[0] > 0:
+            acts += ops.mlp_chain(h, ws)
+            h = acts[-1]
+        else:
+            for i, w in enumerate(ws):
+                h = ops.linear(h, w, relu=i < len(ws) - 1)
+                acts.append(h)
         ctx.save_for_backward(*acts[:-1], *ws)
         ctx.n_layers = len(ws)
         return h
@@ -73,6 +79,16 @@ class _MlpFn(torch.autograd.Function):
         acts, ws = ctx.saved_tensors[:n], ctx.saved_tensors[n:]
         dz = dy.float().contiguous()
         grads = [None] * n
+        if _MlpFn.fused and dz.shape[0] > 0:
+            # g_l = gradient at layer l's input: needed by dW_{l-1} (l >= 1) and, for l = 0, by the caller
+            need_w = [bool(ctx.needs_input_grad[1 + l]) for l in range(n)]
+            want = [bool(ctx.needs_input_grad[0])] + [need_w[l - 1] for l in range(1, n)]    # what is stored (the walk is whole)
+            g = ops.mlp_chain(dz, list(ws), backward=True, masks=[None] + list(acts[1:]), want=want)
+            ups = g[1:] + [dz]                                   # gradient at layer l's OUTPUT = g_{l+1}
+            for l in range(n):
+                if need_w[l]:
+                    grads[l] = ops.weight_grad(acts[l], ups[l])
+            return (g[0] if ctx.needs_input_grad[0] else None, *grads)
         for l in reversed(range(n)):
             if ctx.needs_input_grad[1 + l]:
                 grads[l] = ops.weight_grad(acts[l], dz)

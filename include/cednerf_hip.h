@@ -484,6 +484,20 @@ int ced_march_all(int64_t n_rays, const float *rays_o, const float *rays_d, cons
                   const uint8_t *hits, int32_t fill, int64_t *packed_info, float *t_starts, float *t_ends,
                   int64_t *ray_indices, int64_t capacity, int64_t *total, void *stream);
 
+/* A whole bias-free ReLU MLP (widths <= 64, <= 6 layers) in one launch per direction: the fused forward / backward of
+ * the tiny-cuda-nn FullyFusedMLP networks the reference trains through (cednerf/model.py:200-222,280-344 under
+ * train_real.py:339-420).  Same per-output MFMA order as ced_linear: the results are those of the layer-by-layer calls.
+ * widths (host) [n_layers + 1]: input width, then each layer's output width; weights (host array of device pointers):
+ * W_l [widths[l+1], widths[l]] row-major.
+ * backward = 0: x [n, widths[0]]; outs[l] (device, [n, widths[l+1]]) receives layer l's output -- ReLU applied on all but
+ *   the last layer (on the last too with relu_last); masks unused.
+ * backward = 1: x = dy [n, widths[n_layers]]; going down from the last layer, outs[l] ([n, widths[l]], may be NULL)
+ *   receives the gradient with respect to layer l's INPUT, multiplied by [masks[l] > 0] where masks[l] (that input, i.e.
+ *   the forward's outs[l-1]) is given -- masks[0] is normally NULL (the network input has no ReLU). */
+int ced_mlp_chain(int64_t n, int32_t n_layers, int32_t backward, const float *x, const int32_t *widths,
+                  const float *const *weights, float *const *outs, const float *const *masks, int32_t relu_last,
+                  void *stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -1750,6 +1750,46 @@ def test_sampling_on_the_native_visibility_pass(oracle, name, alpha_thre):
         assert x.dtype == y.dtype and torch.equal(x, y), nm
 
 
+@pytest.mark.parametrize("widths,n", [((32, 64, 64, 64, 3), 100003), ((32, 64, 16), 4097), ((19, 64, 64, 3), 33),
+                                      ((41, 64, 16), 1), ((7, 5), 1000), ((64, 64, 64, 64, 64, 64, 64), 20011)])
+def test_fused_mlp_chain_equals_layerwise(oracle, widths, n):
+    """ced_mlp_chain (a whole MLP per launch, activations in registers from layer to layer) against the layer-by-layer
+    ced_linear calls it replaces: every activation and every gradient bit for bit; and through autograd (_MlpFn)."""
+    from ced_nerf_amd import ops
+    from ced_nerf_amd.train import _MlpFn
+    g = torch.Generator(device=DEV).manual_seed(len(widths) * 1000 + n)
+    x = torch.randn(n, widths[0], device=DEV, generator=g)
+    ws = [torch.randn(widths[l + 1], widths[l], device=DEV, generator=g) * (1.5 / widths[l] ** 0.5) for l in range(len(widths) - 1)]
+    L = len(ws)
+    acts = ops.mlp_chain(x, ws)
+    h = x
+    for l, w in enumerate(ws):
+        h = ops.linear(h, w, relu=l < L - 1)
+        assert torch.equal(acts[l], h), f"forward layer {l}"
+    dy = torch.randn(n, widths[-1], device=DEV, generator=g)
+    masks = [None] + acts[:-1]
+    gs = ops.mlp_chain(dy, ws, backward=True, masks=masks)
+    dz = dy
+    for l in reversed(range(L)):
+        dz = ops.linear(dz, ws[l], transpose_w=True, mask=masks[l])
+        assert torch.equal(gs[l], dz), f"backward layer {l}"
+    some = ops.mlp_chain(dy, ws, backward=True, masks=masks, want=[l == 0 for l in range(L)])
+    assert torch.equal(some[0], gs[0]) and all(t is None for t in some[1:])
+    # autograd node: fused and layer-wise give the same output and the same parameter / input gradients
+    outs = {}
+    for fused in (True, False):
+        _MlpFn.fused = fused
+        xi = x.clone().requires_grad_(True)
+        wi = [w.clone().requires_grad_(True) for w in ws]
+        y = _MlpFn.apply(xi, *wi)
+        (y * dy).sum().backward()
+        outs[fused] = (y.detach(), xi.grad, [w.grad for w in wi])
+    _MlpFn.fused = True
+    assert torch.equal(outs[True][0], outs[False][0]) and torch.equal(outs[True][1], outs[False][1])
+    for a, b in zip(outs[True][2], outs[False][2]):
+        assert torch.equal(a, b)
+
+
 def test_training_steps_reduce_the_loss(oracle):
     """train.train_step end to end: HIP sampling, HIP hash forward/backward, HIP MLPs (ced_linear / ced_weight_grad),
     HIP compositing forward/backward, Adam.  A student whose hash table was damaged relearns a teacher's renders."""
