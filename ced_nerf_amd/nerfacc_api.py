@@ -210,6 +210,7 @@ class OccGridEstimator(torch.nn.Module):
         self.register_buffer("resolution", resolution)
         self.register_buffer("aabbs", aabbs)
         self.register_buffer("occs", torch.zeros(self.levels * self.cells_per_lvl))
+        self.one_pass_march = True       # sampling / render_image may march in one pass with a capacity from the last call
         self.register_buffer("binaries", torch.zeros([levels] + resolution.tolist(), dtype=torch.bool))
         res = resolution.tolist()
         grid_coords = torch.stack(torch.meshgrid([torch.arange(r) for r in res], indexing="ij"), dim=-1)
@@ -324,19 +325,16 @@ class OccGridEstimator(torch.nn.Module):
     @torch.no_grad()
     def march(self, rays_o, rays_d, near_plane: float = 0.0, far_plane: float = 1e10, t_min=None, t_max=None,
               render_step_size: float = 1e-3, stratified: bool = False, cone_angle: float = 0.0,
-              want_ray_indices: bool = True, fast: Optional[bool] = None):
+              want_ray_indices: bool = True, fast: Optional[bool] = None, near_planes: Optional[torch.Tensor] = None):
         """The marching half of `sampling`: every sample inside occupied cells, all rays to the far plane.
-        Returns (t_starts, t_ends, ray_indices, packed_info).  fast: None = the accelerated one-level walk when it
-        applies, False = ced_traverse_grids."""
+        Returns (t_starts, t_ends, ray_indices, packed_info).  fast: None = the accelerated walk when it applies,
+        False = ced_traverse_grids.  near_planes: the per-ray near planes already drawn (`_near_planes`)."""
         rays_o = rays_o.contiguous(); rays_d = rays_d.contiguous()
-        near_planes = torch.full_like(rays_o[..., 0], fill_value=near_plane)
+        if near_planes is None:
+            near_planes = self._near_planes(rays_o, near_plane, t_min, stratified, render_step_size)
         far_planes = torch.full_like(rays_o[..., 0], fill_value=far_plane)
-        if t_min is not None:
-            near_planes = torch.clamp(near_planes, min=t_min)
         if t_max is not None:
             far_planes = torch.clamp(far_planes, max=t_max)
-        if stratified:
-            near_planes = near_planes + torch.rand_like(near_planes) * render_step_size
         if fast is None:
             fast = t_max is None and rays_o.is_cuda
         if fast:        # the accelerated walk of the frame renderer (same samples, ced_march_all)
@@ -352,12 +350,24 @@ class OccGridEstimator(torch.nn.Module):
             render_step_size, cone_angle)
         return t_starts, t_ends, ray_indices, packed_info
 
+    @staticmethod
+    def _near_planes(rays_o, near_plane, t_min, stratified, render_step_size):
+        """Per-ray near planes of nerfacc's sampling: the constant, clamped by t_min, jittered by one step if stratified."""
+        near_planes = torch.full_like(rays_o[..., 0], fill_value=near_plane)
+        if t_min is not None:
+            near_planes = torch.clamp(near_planes, min=t_min)
+        if stratified:
+            near_planes = near_planes + torch.rand_like(near_planes) * render_step_size
+        return near_planes
+
     def march_onepass(self, rays_o, rays_d, near_plane: float, far_plane: float, render_step_size: float,
-                      cone_angle: float, capacity: int):
+                      cone_angle: float, capacity: int, near_planes: Optional[torch.Tensor] = None):
         """`march` in one pass into arrays of `capacity` samples (ops.march_all_onepass): for a caller that can bound the
         total, e.g. by the previous frame's.  Returns (t_starts, t_ends, packed_info, total [device int64])."""
         rays_o = rays_o.contiguous(); rays_d = rays_d.contiguous()
-        near_planes = torch.full_like(rays_o[..., 0], fill_value=near_plane)
+        if near_planes is None:
+            near_planes = torch.full_like(rays_o[..., 0], fill_value=near_plane)
+        near_planes = near_planes.contiguous()
         ev = (None, None, None)
         if self.binaries.shape[0] > 1:
             t_mins, t_maxs, hits = ray_aabb_intersect(rays_o, rays_d, self.aabbs)
@@ -378,16 +388,36 @@ class OccGridEstimator(torch.nn.Module):
         every marched sample, bit for bit (tests/test_gpu_parity.py)."""
         native = (sigma_field is not None and rays_o.is_cuda and (alpha_thre > 0.0 or early_stop_eps > 0.0)
                   and early_stop_eps > 0.0)
-        t_starts, t_ends, ray_indices, packed_info = self.march(rays_o, rays_d, near_plane, far_plane, t_min, t_max,
-                                                                render_step_size, stratified, cone_angle,
-                                                                want_ray_indices=not native)
         if native:
             fld, ts, per_ray = sigma_field
             thre = float(alpha_thre)
             if thre > 0.0:
                 thre = min(thre, self.occs.mean().item())
-            return ops.sampling_native(fld._descriptor(), rays_o.contiguous(), rays_d.contiguous(), packed_info, t_starts,
-                                       t_ends, early_stop_eps, thre, ts.reshape(-1).float().contiguous(), per_ray)
+            rays_o = rays_o.contiguous(); rays_d = rays_d.contiguous()
+            near_planes = self._near_planes(rays_o, near_plane, t_min, stratified, render_step_size)
+            tq = ts.reshape(-1).float().contiguous()
+            # one-pass march into arrays sized by the last batch of this size (batches of a training run march about the
+            # same number of samples); a batch that does not fit is redone with the exact two-pass march
+            hints = self.__dict__.setdefault("_march_totals", {})
+            n = rays_o.shape[0]
+            hint = hints.get(n)
+            if hint is not None and t_max is None and self.one_pass_march:
+                cap = int(hint * 1.25) + 65536
+                t0, t1, packed, total_dev = self.march_onepass(rays_o, rays_d, near_plane, far_plane, render_step_size,
+                                                               cone_angle, cap, near_planes=near_planes)
+                out = ops.sampling_native(fld._descriptor(), rays_o, rays_d, packed, t0, t1, early_stop_eps, thre, tq, per_ray)
+                total = int(total_dev.item())
+                hints[n] = total
+                if total <= cap:
+                    return out
+            t_starts, t_ends, _, packed_info = self.march(rays_o, rays_d, near_plane, far_plane, t_min, t_max, render_step_size,
+                                                          stratified, cone_angle, want_ray_indices=False,
+                                                          near_planes=near_planes)
+            hints[n] = int(t_starts.shape[0])
+            return ops.sampling_native(fld._descriptor(), rays_o, rays_d, packed_info, t_starts, t_ends, early_stop_eps, thre,
+                                       tq, per_ray)
+        t_starts, t_ends, ray_indices, packed_info = self.march(rays_o, rays_d, near_plane, far_plane, t_min, t_max,
+                                                                render_step_size, stratified, cone_angle)
         if (alpha_thre > 0.0 or early_stop_eps > 0.0) and (sigma_fn is not None or alpha_fn is not None):
             alpha_thre = min(alpha_thre, self.occs.mean().item())
             if alpha_fn is not None:

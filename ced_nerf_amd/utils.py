@@ -51,7 +51,6 @@ trunc_exp = _TruncExp.apply
 
 
 _EVAL_PASS_RAYS = 1 << 21     # rays per internal eval pass of render_image
-_EXACT_MARCH_ONLY = False     # True: render_image never uses the one-pass march with a capacity from the previous frame
 
 
 def _flatten_rays(rays: Rays):
@@ -125,7 +124,7 @@ def render_image(
             hints = estimator.__dict__.setdefault("_march_totals", {})
             hint = hints.get(n_pass)
             out = None
-            if hint is not None and not _EXACT_MARCH_ONLY:
+            if hint is not None and estimator.one_pass_march:
                 cap = int(hint * 1.25) + 65536
                 t_all0, t_all1, packed_all, total_dev = estimator.march_onepass(
                     chunk_rays.origins, chunk_rays.viewdirs, near_plane, far_plane, render_step_size, cone_angle, cap)

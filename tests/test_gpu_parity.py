@@ -1748,6 +1748,18 @@ def test_sampling_on_the_native_visibility_pass(oracle, name, alpha_thre):
     assert b[0].numel() > 1000
     for x, y, nm in zip(a, b, ("ray_indices", "t_starts", "t_ends")):
         assert x.dtype == y.dtype and torch.equal(x, y), nm
+    # the second batch of a size marches in one pass (capacity from the first); one that does not fit is redone exactly
+    n = o.shape[0]
+    marched = est._march_totals[n]
+    torch.manual_seed(9)
+    c = est.sampling(o, d, sigma_field=(fused, ts, True), **kw)
+    est._march_totals[n] = 1
+    torch.manual_seed(9)
+    e = est.sampling(o, d, sigma_field=(fused, ts, True), **kw)
+    assert est._march_totals[n] == marched and (marched > 65537 + 1 or name != "dnerf")
+    for other in (c, e):
+        for x, y, nm in zip(other, b, ("ray_indices", "t_starts", "t_ends")):
+            assert torch.equal(x, y), nm
 
 
 @pytest.mark.parametrize("widths,n", [((32, 64, 64, 64, 3), 100003), ((32, 64, 16), 4097), ((19, 64, 64, 3), 33),
