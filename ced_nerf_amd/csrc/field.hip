@@ -493,6 +493,72 @@ struct HashBwdArgs {
     uint32_t res[CED_MAX_LEVELS], offset[CED_MAX_LEVELS], size[CED_MAX_LEVELS], hashed[CED_MAX_LEVELS];
 };
 
+// Table gradient, second form (round 2): FOUR adjacent lanes = (x corner, feature) of one sample's entry pair, one level
+// per blockIdx.y.  The two x corners of a (y, z) corner are adjacent table entries whenever the cell's x index is even
+// (dense levels: always adjacent; hashed levels: (x ^ h) and ((x + 1) ^ h) differ in bit 0 only), so the four lanes add
+// into 16 contiguous bytes and the memory side sees ONE request where the first form (hash_backward_kernel<., true>,
+// one corner per instruction) sent two.  Runs of consecutive samples with the same entry are still summed across the
+// wave first (segmented scan, stride 4).  The atomics are what bounds this kernel (requests, not bytes).
+__global__ __launch_bounds__(256) void hash_table_grad_kernel(HashBwdArgs A)
+{
+    const int64_t gid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int64_t i = gid >> 2;
+    const int feat = (int)(gid & 1), cx = (int)((gid >> 1) & 1);
+    const int l = (int)blockIdx.y;
+    const int lane = threadIdx.x & 63;
+    uint32_t pend_idx[4];
+    float pend_val[4];
+#pragma unroll
+    for (int c = 0; c < 4; ++c) { pend_idx[c] = 0xffffffffu; pend_val[c] = 0.0f; }
+    if (i < A.n) {
+        const float g0 = A.dy[(i * A.n_levels + l) * 2], g1 = A.dy[(i * A.n_levels + l) * 2 + 1];
+        if (g0 != 0.0f || g1 != 0.0f) {
+            const float sc = A.scale[l];
+            uint32_t g[3];
+            float fr[3], om[3];
+#pragma unroll
+            for (int a = 0; a < 3; ++a) {
+                const float xa = __builtin_fminf(__builtin_fmaxf(A.x[3 * i + a], 0.0f), 1.0f);
+                const float pos = xa * sc + 0.5f;
+                const float fl = __builtin_floorf(pos);
+                g[a] = (uint32_t)fl;
+                fr[a] = pos - fl;
+                om[a] = 1.0f - fr[a];
+            }
+            const uint32_t res = A.res[l], size = A.size[l], off = A.offset[l];
+            const bool hashed = A.hashed[l] != 0;
+            const float gv = feat ? g1 : g0;
+            const uint32_t px = g[0] + cx;
+            const float wx = cx ? fr[0] : om[0];
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                const uint32_t py = g[1] + (c & 1), pz = g[2] + (c >> 1);
+                const float wy = (c & 1) ? fr[1] : om[1], wz = (c & 2) ? fr[2] : om[2];
+                const float w = (wx * wy) * wz;                          // the forward's weight: (wx * wy) * wz
+                uint32_t idx = hashed ? (px ^ (py * 2654435761u) ^ (pz * 805459861u)) : (px + py * res + pz * res * res);
+                pend_idx[c] = off + idx % size;
+                pend_val[c] = w * gv;
+            }
+        }
+    }
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+        const uint32_t idx = pend_idx[c];
+        float v = pend_val[c];
+        const uint32_t prev = __shfl_up(idx, 4, 64);
+        int head = (lane < 4 || prev != idx) ? 1 : 0;
+#pragma unroll
+        for (int d = 4; d < 64; d <<= 1) {
+            const float v_up = __shfl_up(v, d, 64);
+            const int h_up = __shfl_up(head, d, 64);
+            if (lane >= d && !head) { v += v_up; head |= h_up; }
+        }
+        const uint32_t next = __shfl_down(idx, 4, 64);
+        const bool last = lane >= 60 || next != idx;
+        if (last && idx != 0xffffffffu && v != 0.0f) unsafeAtomicAdd(A.grad_table + (size_t)idx * 2 + feat, v);
+    }
+}
+
 // LEVEL_MAJOR: blockIdx.y = level, consecutive lanes = consecutive samples -- a wave's atomics then fall into one
 // level's region and, for ray-ordered samples, into few cache lines (used for the table gradient).  Otherwise 16
 // consecutive lanes = the 16 levels of one sample, whose position-gradient contributions are summed inside the
@@ -596,6 +662,7 @@ int g_field_spread_tiles = 1;     // field kernels: deal tiles across all CUs fi
 bool g_march_early_out = true;    // frame renderer: conservative brick-level early-out (ced_set_option)
 
 // launch-geometry variant of the field kernel (ced_set_option("field_variant", v))
+static int g_hash_grad_form = [] { const char *e = getenv("CED_HASH_GRAD_FORM"); return e ? atoi(e) : 1; }();   // 0: one corner per instruction
 static int g_field_variant = [] { const char *e = getenv("CED_FIELD_VARIANT"); return e ? atoi(e) : 2; }();
 
 static int validate_hash(const ced_hash_desc *h, const char *who)
@@ -720,6 +787,11 @@ extern "C" int ced_set_option(const char *key, int value)
     if (strcmp(key, "half_variant") == 0) {
         CED_REQUIRE(value >= 0 && value <= 2, "set_option: half_variant must be 0..2");
         ced::set_half_variant(value);
+        return CED_OK;
+    }
+    if (strcmp(key, "hash_grad_form") == 0) {
+        CED_REQUIRE(value == 0 || value == 1, "set_option: hash_grad_form must be 0 or 1");
+        ced::g_hash_grad_form = value;
         return CED_OK;
     }
     if (strcmp(key, "field_variant") == 0) {
@@ -878,8 +950,13 @@ extern "C" int ced_hash_encode_backward(const ced_hash_desc *desc, int64_t n, co
     }
     const dim3 block(256);
     // table gradient: level-major; position gradient (optional): sample-major, no atomics
-    const dim3 grid_t((unsigned)((2 * n + 255) / 256), (unsigned)desc->n_levels);
-    hipLaunchKernelGGL((ced::hash_backward_kernel<false, true>), grid_t, block, 0, (hipStream_t)stream, A);
+    if (ced::g_hash_grad_form == 0) {
+        const dim3 grid_t((unsigned)((2 * n + 255) / 256), (unsigned)desc->n_levels);
+        hipLaunchKernelGGL((ced::hash_backward_kernel<false, true>), grid_t, block, 0, (hipStream_t)stream, A);
+    } else {
+        const dim3 grid_t((unsigned)((4 * n + 255) / 256), (unsigned)desc->n_levels);
+        hipLaunchKernelGGL(ced::hash_table_grad_kernel, grid_t, block, 0, (hipStream_t)stream, A);
+    }
     if (dx) {
         const dim3 grid_x((unsigned)((n * 16 + 255) / 256));
         if (A.table_dtype) hipLaunchKernelGGL((ced::hash_backward_kernel<true, false>), grid_x, block, 0, (hipStream_t)stream, A);
