@@ -787,6 +787,34 @@ def test_render_image_several_internal_passes(oracle, monkeypatch):
         assert_bitexact(N(ge["weights"]), we["weights"], "weights")
 
 
+@pytest.mark.parametrize("prec,table", [("f16x2", np.float32), ("f16", np.float16)])
+def test_render_image_native_pass_in_the_half_modes(oracle, prec, table):
+    """The native render_image pass on the half-precision field kernels (their per-sample arrays are addressed through
+    the same device-side window): identical to the staged composition in the same arithmetic mode, bit for bit."""
+    from ced_nerf_amd import synthetic as S
+    from ced_nerf_amd.model import DNGPradianceField
+    from ced_nerf_amd.nerfacc_api import OccGridEstimator
+    from ced_nerf_amd.utils import Rays, render_image
+    sc = S.make_scene("dnerf", 160, 120, "trained", table_dtype=table, log2_hashmap_size=17)
+    cfg = sc["cfg"]
+    f = DNGPradianceField.from_params(sc["params"], DEV, mlp_precision=prec).eval()
+    est = OccGridEstimator(cfg["aabb"], cfg["grid_resolution"], cfg["grid_levels"]).to(DEV)
+    est.set_binaries(T(sc["binaries"]))
+    rays = Rays(T(sc["origins"]), T(sc["viewdirs"]))
+    rk = dict(sc["render"]); rk["render_bkgd"] = T(rk["render_bkgd"])
+    ts = T(sc["timestamps"])
+    a = render_image(f, est, rays, timestamps=ts, native=True, **rk)
+    a2 = render_image(f, est, rays, timestamps=ts, native=True, **rk)            # one-pass march this time
+    b = render_image(f, est, rays, timestamps=ts, native=False, **rk)
+    for other in (a2, b):
+        assert a[3] == other[3] > 10000 and len(a[4]) == len(other[4])
+        for i in range(3):
+            assert torch.equal(a[i], other[i])
+        for x, y in zip(a[4], other[4]):
+            for k in y:
+                assert torch.equal(x[k], y[k]), (prec, k)
+
+
 def test_render_image_native_pass_empty_and_ragged(oracle):
     """Rays that miss the grid (no samples), a pass smaller than a chunk, and zero rays."""
     from ced_nerf_amd.utils import Rays, render_image
