@@ -392,7 +392,7 @@ int64_t ced_render_image_test_workspace_bytes(int64_t n_rays, int32_t n_grids, i
  * iteration's N_samples = clamp(N_rays // N_alive, min, 64) ON THE DEVICE, and the background / depth
  * normalisation at the end.  Same schedule and per-ray sample sets as the reference loop; unlike it
  * (utils.py:231: one device->host sync per iteration) the host never waits for an iteration: it enqueues up to
- * CED_FRAME_RUN_AHEAD (default 2) iterations beyond the last one whose plan it has seen published in `host_stats`.
+ * CED_FRAME_RUN_AHEAD (default 1) iterations beyond the last one whose plan it has seen published in `host_stats`.
  * `alpha_thre` is not a parameter because the reference ignores it in this function.
  *   rays_o, rays_d [n_rays,3]; binaries [n_grids,res,res,res] bytes; aabbs [n_grids,6];
  *   accel: device, from ced_build_occupancy_accel for these binaries, or NULL (built inside the call);
