@@ -10,6 +10,8 @@
 // geometry closes on itself: lane (g, c) ends a layer holding outputs 16 nb + 4 g + r of sample c, and as B operand of
 // the next layer it must supply inputs 16 q + 4 g + s -- the same elements (nb = q, r = s).  Same MFMA order per
 // output as ced_linear => the same bits.  Widths <= 64, <= 6 layers; all layers' fragments live in LDS (<= 96 KB).
+#include <cstdlib>
+
 #include "ced_common.hpp"
 
 namespace ced {
@@ -204,7 +206,14 @@ extern "C" int ced_mlp_chain(int64_t n, int32_t n_layers, int32_t backward, cons
     }
     const int64_t n_tiles = (n + 31) / 32;
     int64_t blocks = (n_tiles + 3) / 4;
-    if (blocks > 1024) blocks = 1024;
+    // persistent over tiles: no more workgroups than are resident at once (4 per CU by registers, fewer when the layers'
+    // fragments fill the LDS: a late second round of workgroups would only lengthen the launch)
+    int per_cu = (int)((160 * 1024) / (lds > 0 ? lds : 1));
+    if (per_cu > 4) per_cu = 4;
+    if (per_cu < 1) per_cu = 1;
+    static const int blocks_env = [] { const char *e = getenv("CED_MLP_MAX_BLOCKS"); return e ? atoi(e) : 0; }();
+    const int64_t cap = blocks_env > 0 ? blocks_env : 256 * per_cu;
+    if (blocks > cap) blocks = cap;
     hipLaunchKernelGGL(ced::mlp_chain_kernel, dim3((unsigned)blocks), dim3(256), lds, (hipStream_t)stream, A);
     return ced::check_launch("mlp_chain");
 }
