@@ -465,6 +465,10 @@ __global__ __launch_bounds__(256) void hash_encode_kernel(HashArgs A)
     float t_frac = 0.0f;
     if constexpr (TEMPORAL) temporal_keyframe(A.t ? A.t[i] : 0.0f, k_lo, t_frac);
     float *o = A.out + i * 2 * A.n_levels;
+    // a lane owns one 8 * n_levels-byte output row: two levels' features leave as one 16-byte store when the row is
+    // aligned (8-byte stores of 64 lanes in 64 rows wrote five times the bytes: 32-byte sectors written a quarter full)
+    const bool vec = (A.n_levels & 1) == 0 && (reinterpret_cast<uintptr_t>(A.out) & 15) == 0;
+    float p0 = 0.0f, p1 = 0.0f;
 #pragma unroll
     for (int l = 0; l < CED_MAX_LEVELS; ++l) {
         if (l < A.n_levels) {
@@ -473,8 +477,15 @@ __global__ __launch_bounds__(256) void hash_encode_kernel(HashArgs A)
             float f0, f1;
             if (A.hashed[l]) hash_level<F16, TEMPORAL, 2>(L, A.table, x, k_lo, t_frac, f0, f1);      // level-uniform
             else hash_level<F16, TEMPORAL, 1>(L, A.table, x, k_lo, t_frac, f0, f1);
-            o[2 * l] = f0;
-            o[2 * l + 1] = f1;
+            if (!vec) {
+                o[2 * l] = f0;
+                o[2 * l + 1] = f1;
+            } else if ((l & 1) == 0) {
+                p0 = f0; p1 = f1;
+            } else {
+                typedef float of4 __attribute__((ext_vector_type(4)));
+                *reinterpret_cast<of4 *>(o + 2 * (l - 1)) = of4{ p0, p1, f0, f1 };
+            }
         }
     }
 }
