@@ -58,10 +58,14 @@ def parse():
                          "iteration, each on its own schedule; 1 = ced_render_image_test per frame")
     ap.add_argument("--frames-in-flight", type=int, default=3,
                     help="independent frames rendered concurrently per GPU (own stream + host thread each)")
-    ap.add_argument("--scaling", default="weak", choices=["weak", "strong"],
-                    help="weak: a step renders frames_in_flight x frames_per_call frames PER GPU (per-GPU work fixed); "
-                         "strong: that many frames in total, every frame's rays dealt tile-cyclically over the GPUs and "
-                         "every frame's shard on its own render_image_test schedule (total work fixed)")
+    ap.add_argument("--scaling", default=None, choices=["weak", "strong"],
+                    help="strong (default with several GPUs): a step renders frames_in_flight x frames_per_call frames IN "
+                         "TOTAL, every frame's rays dealt tile-cyclically over the GPUs (total work fixed: value(N) / "
+                         "value(1) is the speed-up); weak: that many frames PER GPU (per-GPU work fixed).  Either way a "
+                         "unit of a call is one rank's share of ONE frame and every frame runs the image-global "
+                         "render_image_test schedule (survivor counts all-reduced per iteration), so the gathered frames "
+                         "are bit-identical to single-GPU frames.  With several GPUs the other scaling is measured "
+                         "briefly afterwards and reported beside the main figure (`other_scaling`)")
     ap.add_argument("--min-seconds", type=float, default=2.0,
                     help="after the contractual K-step window, further K-step windows are timed until this much time has "
                          "been measured in all (at least 5, at most 24 windows): median / p10 / p90 in `windows`; "
@@ -176,17 +180,14 @@ def main():
     # A step renders `lanes` x `world` frames of a turntable video (consecutive azimuths): every lane is
     # one frame per GPU, its rays dealt tile-cyclically over the ranks; the lanes run concurrently.
     lanes = max(1, args.frames_in_flight)
-    per_call = max(1, min(8, args.frames_per_call))
-    # weak scaling: a unit of a call is this rank's share of `world` consecutive frames (per-GPU work fixed);
-    # strong scaling: a unit is this rank's share of ONE frame (total work fixed)
+    if args.scaling is None:
+        args.scaling = "strong" if world > 1 else "weak"
+    per_call = max(1, min(64 // world, args.frames_per_call))
+    # A unit of a native call is this rank's share of ONE frame in both modes (the frame's loop is the whole image's,
+    # cednerf/utils.py:231-235).  strong: a call holds per_call frames (total work fixed: each rank renders 1/world of
+    # every frame); weak: per_call * world frames (per-GPU work fixed: the launches keep their single-GPU size).
+    frames_per_call_of = lambda scaling: per_call * (world if scaling == "weak" else 1)
     wf = world if args.scaling == "weak" else 1
-    if per_call > 1:
-        # several frames per call need every rank's share of every frame group to be the same number of rays
-        # (true for 800x800 on 1/2/4/8 GPUs); otherwise fall back to one frame per call
-        ids = cdist.tile_cyclic_assignment(per_call * wf, args.height, args.width, world)[1]
-        group = wf * args.height * args.width
-        if len({len(s) for s in ids}) != 1 or any(len(set(np.bincount(s // group, minlength=per_call).tolist())) != 1 for s in ids):
-            per_call = 1
     tdt = np.float16 if args.table_dtype == "f16" else np.float32
     n_frames = lanes * per_call * wf
     sc = S.make_scene(args.scene, args.width, args.height, args.regime, azim_deg=30.0, table_dtype=tdt)
@@ -199,7 +200,8 @@ def main():
         o, d = S.make_camera_rays(args.width, args.height, cfg["camera_angle_x"], c2w, cfg["opengl"])
         return {"origins": o, "viewdirs": d}
 
-    frames = [frame_rays(f) for f in range(n_frames)]
+    n_frames_max = lanes * per_call * world
+    frames = [frame_rays(f) for f in range(n_frames_max if world > 1 else n_frames)]
     field = DNGPradianceField.from_params(sc["params"], dev, mlp_precision=args.mlp_precision).eval()
     field._descriptor()
     est = OccGridEstimator(cfg["aabb"], cfg["grid_resolution"], cfg["grid_levels"]).to(dev)
@@ -207,12 +209,23 @@ def main():
     rk = dict(sc["render"]); rk["render_bkgd"] = T(rk["render_bkgd"])
     ts = T(sc["timestamps"])
     from ced_nerf_amd import ops
+    # every lane's native calls run concurrently on their own threads and each holds one small all-reduce per
+    # iteration: one process group (communicator) per lane, created by all ranks in the same order
+    lane_groups = [dist.new_group(backend=backend) if world > 1 else None for _ in range(lanes)]
+
+    def make_lanes(wf_):
+        out = []
+        for l in range(lanes):
+            fr = frames[l * per_call * wf_:(l + 1) * per_call * wf_]
+            r_ = cdist.ShardedRenderer(field, est, world, rank, dev, max_samples=args.max_samples, render_kwargs=rk,
+                                       tile_order=os.environ.get("CED_TILE_ORDER", "1") != "0", units=per_call,
+                                       schedule_group=lane_groups[l])
+            r_.set_rays(torch.stack([T(f["origins"]) for f in fr]), torch.stack([T(f["viewdirs"]) for f in fr]))
+            out.append(r_)
+        return out
+
     lane_renderers, tracers = [], []
-    for l in range(lanes):
-        fr = frames[l * per_call * wf:(l + 1) * per_call * wf]
-        r = cdist.ShardedRenderer(field, est, world, rank, dev, max_samples=args.max_samples, render_kwargs=rk,
-                                  tile_order=os.environ.get("CED_TILE_ORDER", "1") != "0", units=per_call)
-        r.set_rays(torch.stack([T(f["origins"]) for f in fr]), torch.stack([T(f["viewdirs"]) for f in fr]))
+    for l, r in enumerate(make_lanes(wf)):
         # HIP events around every field launch; one event set per timed step so nothing is read back
         # (hipEventElapsedTime) inside the timed region
         tracers.append([ops.FrameTracer(capacity=96, with_events=True) for _ in range(min(args.steps, 24))])
@@ -361,39 +374,58 @@ def main():
             t2sum = tt2.clone(); dist.all_reduce(t2sum, op=dist.ReduceOp.SUM)
             tt2 = torch.stack([t2max[0], t2sum[1]])
         others[prec] = {"value": float(tt2[1]) / float(tt2[0]), "unit": "samples/s", "steps": k,
-                        "ms_per_frame": 1e3 * float(tt2[0]) / k / (lanes * per_call),
+                        "ms_per_frame": 1e3 * float(tt2[0]) / k / n_frames,
                         "rays_per_sec": n_frames * args.width * args.height * k / float(tt2[0])}
     field.set_mlp_precision(args.mlp_precision)
     field._descriptor()
-    if rank != 0:
-        if world > 1:
-            dist.destroy_process_group()
-        return
-    n_rays_step = n_frames * args.width * args.height          # frames of a step x rays per frame, over all ranks
-    # latency of ONE frame rendered alone (no other frame in flight), for reference (field launches on all CUs again)
+    # several GPUs: the same steps in the OTHER scaling mode, briefly (same barrier / max-over-ranks discipline)
+    other_scaling = None
+    if world > 1:
+        other = "weak" if args.scaling == "strong" else "strong"
+        wf_o = world if other == "weak" else 1
+        lanes_o = make_lanes(wf_o)
+        pipe_o = cdist.PipelinedRenderer(lanes_o, async_gather=True,
+                                         field_max_blocks=int(os.environ.get("CED_FIELD_MAX_BLOCKS", "256")))
+        pipe_o.render(ts)
+        pipe_o.wait_gathers()
+        dist.barrier()
+        torch.cuda.synchronize()
+        k = max(1, min(args.steps, 6))
+        t_a = time.perf_counter()
+        rows_o = pipe_o.render_steps(ts, k)
+        s_loc = sum(o["local_samples"] for row in rows_o for o in row)
+        del rows_o
+        torch.cuda.synchronize()
+        dist.barrier()
+        d_o, s_o = reduce_window(time.perf_counter() - t_a, s_loc)
+        nf_o = lanes * per_call * wf_o
+        other_scaling = {"scaling": other, "value": s_o / d_o, "unit": "samples/s", "steps": k, "frames_per_step": nf_o,
+                         "rays_per_sec": nf_o * args.width * args.height * k / d_o, "ms_per_step": 1e3 * d_o / k}
+        del pipe_o, lanes_o
+    # latency of ONE frame rendered alone (no other frame in flight; field launches on all CUs again).  With several
+    # GPUs the frame is sharded like every other (image-global schedule), so ALL ranks render it together.
     for r_ in lane_renderers:
         r_.field_max_workgroups = 0          # one frame alone: field launches on all CUs
     torch.cuda.synchronize()
-    t1 = time.perf_counter()
     single_field = {"ms": 0.0, "launches": 0, "units": 0.0}
     single_ms, single_stats = None, None
     if not args.no_single_frame:
-        alone = lane_renderers[0]
-        if per_call > 1:                                # one frame (per GPU) per call, as ced_render_image_test renders it
-            alone = cdist.ShardedRenderer(field, est, world, rank, dev, max_samples=args.max_samples, render_kwargs=rk,
-                                          tile_order=os.environ.get("CED_TILE_ORDER", "1") != "0")
-            alone.set_rays(torch.stack([T(f["origins"]) for f in frames[:world]]), torch.stack([T(f["viewdirs"]) for f in frames[:world]]))
+        alone = cdist.ShardedRenderer(field, est, world, rank, dev, max_samples=args.max_samples, render_kwargs=rk,
+                                      tile_order=os.environ.get("CED_TILE_ORDER", "1") != "0", schedule_group=lane_groups[0])
+        alone.set_rays(torch.stack([T(f["origins"]) for f in frames[:1]]), torch.stack([T(f["viewdirs"]) for f in frames[:1]]))
         alone.tracer = tracers[0][0]
         alone.render_local(ts)                          # first call on this stream allocates its workspace
         torch.cuda.synchronize()
         for _ in range(5):                              # with HIP events around the field launches (roofline_single_frame)
-            alone.render_local(ts)                      # this rank's shard only: the other ranks have left by now
+            alone.render_local(ts)
             ms = tracers[0][0].field_ms()
             single_field["ms"] += sum(ms); single_field["launches"] += len(ms)
             single_field["units"] += float(sum(it["n_new"] for it in tracers[0][0].iterations()))
         alone.tracer = None
         single_times = []
         for _ in range(20):                             # the latency itself: untraced, every frame timed on its own
+            if world > 1:
+                dist.barrier()
             torch.cuda.synchronize()
             t1 = time.perf_counter()
             alone.render_local(ts)
@@ -402,6 +434,20 @@ def main():
         single_ms = float(np.median(single_times))
         single_stats = {"median": single_ms, "p10": float(np.quantile(single_times, 0.1)),
                         "p90": float(np.quantile(single_times, 0.9)), "frames": len(single_times)}
+    comm_info = None
+    if world > 1:
+        comm_info = {"backend": dist.get_backend(), "ranks": dist.get_world_size(),
+                     "schedule_exchange": "per iteration and call one all-reduce(sum) of [frames_per_call] int64 on the "
+                                          "call's stream, one process group per call in flight",
+                     "schedule_allreduces_last_call": int(getattr(lane_renderers[0].exchange, "calls", 0))}
+    if rank != 0:
+        if world > 1:
+            dist.barrier()                  # rank 0's checks below render whole frames alone: nothing collective is left
+            dist.destroy_process_group()
+        return
+    if world > 1:
+        dist.barrier()
+    n_rays_step = n_frames * args.width * args.height          # frames of a step x rays per frame, over all ranks
     # secondary entry (a2): cednerf.utils.render_image (eval) on frame 0 -- `sampling` with its visibility filter, then
     # `rendering`; the native pass evaluates the field once per sample and stops rays at the filter's threshold
     render_image_entry = None
@@ -441,7 +487,7 @@ def main():
                   "f16": "f16 MLP operands, fp32 accumulate; rest f32"}[args.mlp_precision],
         "mlp_precision": args.mlp_precision, "data": "synthetic",
         "rays_per_sec": n_rays_step * args.steps / dt,
-        "ms_per_frame": 1e3 * dt / args.steps / (lanes * per_call),
+        "ms_per_frame": 1e3 * dt / args.steps / n_frames,
         "single_frame_latency_ms": single_ms, "single_frame_latency_stats_ms": single_stats,
         "render_image": render_image_entry,
         "windows": {"n": len(window_rates), "steps_each": args.steps, "seconds": timed, "unit": "samples/s",
@@ -452,13 +498,17 @@ def main():
         "config": {"workload": f"{args.scene} {args.width}x{args.height} render_image_test max_samples={args.max_samples}, "
                                f"hash L=16 F=2 T=2^21 {'fp16' if fp16 else 'fp32'} table, 64-wide MLPs, "
                                f"{args.regime} params, occupancy 128^3 x{cfg['grid_levels']}",
-                   "frames_per_step": n_frames, "frames_in_flight_per_gpu": lanes * per_call, "frames_per_call": per_call,
-                   "rays_per_step": n_rays_step,
-                   "parallelism": f"{lanes} call(s) in flight per GPU x {per_call} frame(s) per call, every frame on its own "
-                                  f"render_image_test schedule; each frame's rays tile-cyclic over {world} GPU(s) + "
-                                  f"all-gather of pixels ({args.scaling} scaling: "
-                                  f"{'a unit = one rank share of ' + str(world) + ' consecutive frames' if args.scaling == 'weak' else 'a unit = one rank share of one frame'})"},
+                   "frames_per_step": n_frames, "frames_in_flight_per_gpu": lanes * per_call * wf,
+                   "frames_per_call": per_call * wf, "rays_per_step": n_rays_step,
+                   "parallelism": f"{lanes} call(s) in flight per GPU x {per_call * wf} frame(s) per call, every frame on the "
+                                  f"render_image_test schedule of the WHOLE image; each frame's rays tile-cyclic over "
+                                  f"{world} GPU(s) (a unit of a call = one rank's share of one frame), survivor counts "
+                                  f"all-reduced per iteration, one all-gather of pixels per call ({args.scaling} scaling)"},
     }
+    if other_scaling is not None:
+        line["other_scaling"] = other_scaling
+    if comm_info is not None:
+        line["comm"] = comm_info
     fk = prof.get("field", None)
     if fk and fk["launches"] > 0:
         # With several frames in flight their field launches share the chip, so a launch's own
@@ -542,15 +592,15 @@ def main():
             v_["parity"] = notes[k_]
         line["other_mlp_precisions"] = others
     if world > 1 and last_row is not None:
-        # the exchange, checked: lane 0's gathered frames of the last timed step (every rank's shard, all-gathered and
-        # un-permuted) against the same frames rendered whole by this rank alone.  A shard runs its own image-global
-        # schedule, so sample counts differ (reported) and pixels agree to the north-star 1e-4, not bit for bit.
+        # the exchange, checked: lane 0's gathered frames of the last timed step (every rank's shard on the image-global
+        # schedule, all-gathered and un-permuted) against the same frames rendered whole by this rank alone: the same
+        # bits and the same sample totals, not a tolerance
         from ced_nerf_amd.utils import render_image_test
         renderer.wait_gathers()
         torch.cuda.synchronize()
         o0 = last_row[0]
         worst = {"rgb": 0.0, "opacity": 0.0, "depth": 0.0}
-        single_total, n_over, n_pix = 0, 0, 0
+        single_total, n_over, n_pix, equal = 0, 0, 0, True
         n_check = min(o0["rgb"].shape[0], 3)
         for k in range(n_check):
             fk_ = frames[k]
@@ -560,19 +610,22 @@ def main():
             over = None
             for nm, a, b in (("rgb", o0["rgb"][k], single[0]), ("opacity", o0["opacity"][k], single[1]),
                              ("depth", o0["depth"][k], single[2])):
+                equal = equal and bool(torch.equal(a, b.reshape(a.shape)))
                 dlt = (a - b.reshape(a.shape)).abs().amax(dim=-1)
                 worst[nm] = max(worst[nm], float(dlt.max()))
-                if nm != "opacity":
-                    over = (dlt > 1e-4) if over is None else (over | (dlt > 1e-4))
+                over = (dlt > 1e-4) if over is None else (over | (dlt > 1e-4))
             n_over += int(over.sum()); n_pix += int(over.numel())
-        # A shard's schedule restarts every ray's march at other termination planes than the whole frame's does; the
-        # reference's DDA set-up is redone at every restart (nerfacc), so a sample whose mid-point lies within rounding
-        # of a cell boundary can be in one sample set and not in the other: rare pixels (about one in 4e5) differ by
-        # one low-weight sample, i.e. by more than the early-stop bound of 1e-4.
+        # sample total of the gathered call (all ranks, all its frames) against single-rank renders of ALL its frames
+        gathered_total = int(o0["total_samples_tensor"].item()) if o0.get("total_samples_tensor") is not None else None
+        for k in range(n_check, o0["rgb"].shape[0]):
+            fk_ = frames[k]
+            single_total += int(render_image_test(args.max_samples, field, est, Rays(T(fk_["origins"]), T(fk_["viewdirs"])),
+                                                  timestamps=ts, **rk)[3])
         line["gather_check"] = {"frames": n_check, "rgb_max_abs": worst["rgb"], "opacity_max_abs": worst["opacity"],
                                 "depth_max_abs": worst["depth"], "samples_single_rank": single_total,
-                                "pixels": n_pix, "pixels_over_1e-4": n_over,
-                                "ok": bool(n_over <= max(2, n_pix // 50000) and max(worst["rgb"], worst["depth"]) <= 5e-3)}
+                                "samples_gathered": gathered_total, "samples_equal": gathered_total == single_total,
+                                "pixels": n_pix, "pixels_over_1e-4": n_over, "bitexact": bool(equal),
+                                "ok": bool(equal and n_over == 0 and gathered_total == single_total)}
     if not args.no_cpu_baseline:
         line["cpu_baseline"], oracle_out = cpu_baseline(sc, args)
         if world == 1 and args.cpu_stride == 1:

@@ -54,6 +54,18 @@ class FrameTrace(C.Structure):
     ]
 
 
+# ced_exchange_fn: int (*)(void *user, int64_t *counts, int32_t n_counts, int32_t iteration, void *stream)
+EXCHANGE_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_void_p)
+
+
+class ShardExchange(C.Structure):
+    """ced_shard_exchange"""
+    _fields_ = [
+        ("global_rays_per_frame", C.c_int64), ("local_rays", C.c_void_p), ("counts", C.c_void_p),
+        ("reduce", EXCHANGE_FN), ("user", C.c_void_p),
+    ]
+
+
 _vp, _i64, _i32, _f = C.c_void_p, C.c_int64, C.c_int32, C.c_float
 
 # name -> (restype, argtypes); one entry per function declared in include/cednerf_hip.h
@@ -108,6 +120,11 @@ PROTOTYPES = {
     "ced_render_frames_test": (C.c_int, [C.POINTER(FieldDesc), _i32, _i64, _vp, _vp, _vp, _i32, _i32, _vp, _vp, _f, _f, _f, _f,
                                          _f, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _vp, C.POINTER(_i64),
                                          C.POINTER(FrameTrace), _vp, _vp]),
+    "ced_render_frames_test_iterations": (_i32, [_f, _i32]),
+    "ced_render_frames_test_host_bytes": (_i64, [_f, _i32]),
+    "ced_render_frames_test_sharded": (C.c_int, [C.POINTER(FieldDesc), _i32, _i64, _vp, _vp, _vp, _i32, _i32, _vp, _vp, _f, _f, _f,
+                                                 _f, _f, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _vp, C.POINTER(_i64),
+                                                 C.POINTER(FrameTrace), _vp, _vp, C.POINTER(ShardExchange)]),
     "ced_wall_clock_khz": (_i64, []),
     "ced_mlp_chain": (C.c_int, [_i64, _i32, _i32, _vp, C.POINTER(_i32), C.POINTER(_vp), C.POINTER(_vp), C.POINTER(_vp), _i32, _vp]),
     "ced_march_all": (C.c_int, [_i64, _vp, _vp, _vp, _i32, _i32, _vp, _vp, _vp, _f, _f, _f, _vp, _vp, _vp, _i32, _vp, _vp, _vp,

@@ -33,7 +33,7 @@ int build_brick_accel(const uint8_t *binaries, int n_grids, int res, uint8_t *di
 AccelSpec accel_view(const void *accel, int n_grids, int res, bool with_cells);
 
 constexpr int kMaxGrids = 8;
-constexpr int kMaxFrames = 8;       // frames rendered by one call (ced_render_frames_test)
+constexpr int kMaxFrames = 64;      // frames rendered by one call (ced_render_frames_test); one lane of the scheduling wave each
 constexpr int kSlotAlign = 256;     // a frame's ray slots start at a multiple of this: no workgroup straddles two frames
 #ifndef CED_MARCH_THREADS
 #define CED_MARCH_THREADS 128
@@ -44,13 +44,16 @@ constexpr int kCompositeThreads = 256;
 #define CED_COMPOSITE_KU 4
 #endif
 constexpr int kHostLatticeWord = 8;    // host_stats: words 0..2 publish {alive, done, seq}; the lattice table from word 8 on
+constexpr int kHostIterWord = 8 + 128; // sharded calls: {alive here, done, seq} of plan k at word kHostIterWord + 3k
 
 // The plan of ONE iteration, in device memory (written by make_next_plan, read by that iteration's launches).
 // Several frames in one call: the rays of all frames are one array (frame f owns ray ids [f*rays_per_frame,
 // (f+1)*rays_per_frame)); every frame keeps its OWN reference loop (N_samples on its own counts, its own end) and its
 // own alive list; a launch covers the frames' alive rays back to back.
 struct IterPlan {
-    int32_t count[kMaxFrames];       // rays of frame f alive entering the iteration (0: the frame has finished)
+    int32_t count[kMaxFrames];       // rays of frame f alive entering the iteration, in THIS process (0: none left here)
+    int32_t gcount[kMaxFrames];      // the same over all processes that share the frame (= count unless the frame's rays
+                                     // are sharded, ced_shard_exchange); 0: the frame has finished
     int32_t limit[kMaxFrames];       // the frame's N_samples in this iteration (cednerf/utils.py:235)
     int32_t last[kMaxFrames];        // the frame's loop ends after this iteration (max_samples reached, utils.py:229)
     int32_t used[kMaxFrames];        // the frame's iter_samples, this iteration included (utils.py:236)
@@ -69,10 +72,14 @@ struct IterPlan {
 // frame of the workgroup whose first ray slot is s0 (block-uniform), -1 for the padding between two frames
 __device__ __forceinline__ int frame_of_slot(const IterPlan &P, int n_frames, int64_t s0)
 {
-    int f = -1;
-    for (int k = 0; k < n_frames; ++k)
-        if (P.count[k] > 0 && s0 >= P.slot_base[k] && s0 < (int64_t)P.slot_base[k] + P.count[k]) f = k;
-    return f;
+    // slot_base is non-decreasing and a frame without rays shares its base with the next one: the LAST frame whose
+    // base is <= s0 is the only candidate (binary search; n_frames <= 64)
+    int lo = 0, hi = n_frames - 1;
+    while (lo < hi) {
+        const int mid = (lo + hi + 1) >> 1;
+        if ((int64_t)P.slot_base[mid] <= s0) lo = mid; else hi = mid - 1;
+    }
+    return (P.count[lo] > 0 && s0 >= P.slot_base[lo] && s0 < (int64_t)P.slot_base[lo] + P.count[lo]) ? lo : -1;
 }
 
 __global__ __launch_bounds__(256) void frame_times_kernel(int64_t n_rays, int rays_per_frame,
@@ -141,57 +148,90 @@ __global__ __launch_bounds__(256) void frame_prep_single_kernel(int64_t n_rays, 
 // Every frame advances its own reference loop (cednerf/utils.py:227-238): while iter_samples < max_samples and rays
 // are alive, N_samples = clamp(N_rays // N_alive, min, 64), iter_samples += N_samples.  it = -1 writes the plan of
 // iteration 0 (all rays alive); otherwise the plan of iteration it + 1 from the survivor counts of iteration it.
-// Then (alive rays, done) of the new plan go to pinned host memory behind a sequence number.  One thread.
+// Then (alive rays, done) of the new plan go to pinned host memory behind a sequence number.
+// ONE WAVE: lane f works out frame f, the frames' slot ranges are an exclusive prefix sum across the lanes.
+//
+// Sharded frames (ced_shard_exchange): the rays of frame f are dealt over several processes and the reference's loop is
+// ONE loop per image -- N_rays and N_alive in utils.py:235 are the whole image's.  `xcounts` then holds, for every
+// iteration and frame, the survivors summed over the processes (the exchange step between the compositing and this
+// launch), `global_rays` the image's ray count: every process computes the same N_samples, the same last-iteration flag
+// and the same end of the loop, so each ray gets exactly the samples it gets when one process renders the image.
 struct ScheduleArgs {
     IterPlan *plans;
     int it, n_frames, rays_per_frame, min_samples, max_samples;
     long long *host;
     long long seq;
+    const int32_t *local_rays;      // device [n_frames] or NULL: rays of frame f that are real (the rest of its
+                                    // rays_per_frame slots is padding and never alive)
+    const int64_t *xcounts;         // device [(max_iters + 1) * n_frames] or NULL: survivors over all processes
+    int64_t global_rays;            // N_rays of the whole image when sharded, else 0 (= rays_per_frame)
+    long long *host_iter;           // pinned, or NULL: {alive here, done, seq} of EVERY plan, plan k at word 3k
 };
 
 __device__ __forceinline__ void make_next_plan(const ScheduleArgs &S)
 {
+    const int f = threadIdx.x & 63;
     IterPlan &N = S.plans[S.it + 1];
-    int slots = 0;
-    long long samples = 0, alive_total = 0;
-    for (int f = 0; f < kMaxFrames; ++f) {
-        int alive = 0, used = 0;
-        if (f < S.n_frames) {
-            if (S.it < 0) {
-                alive = S.rays_per_frame;
-            } else {
-                IterPlan &P = S.plans[S.it];
-                // the survivor counts were accumulated by device-scope atomics of other workgroups
-                const unsigned long long nx = __hip_atomic_load(&P.next[f], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                alive = (P.last[f] || P.count[f] == 0) ? 0 : (int)(nx & 0xffffffffull);
-                used = P.used[f];
-            }
+    int local = 0, used = 0;
+    long long global = 0;
+    if (f < S.n_frames) {
+        if (S.it < 0) {
+            local = S.local_rays ? S.local_rays[f] : S.rays_per_frame;
+            global = S.global_rays > 0 ? S.global_rays : local;
+        } else {
+            const IterPlan &P = S.plans[S.it];
+            // the survivor counts were accumulated by device-scope atomics of other workgroups
+            const unsigned long long nx = __hip_atomic_load(&P.next[f], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            const bool finished = P.last[f] || P.gcount[f] == 0;
+            local = (finished || P.count[f] == 0) ? 0 : (int)(nx & 0xffffffffull);
+            global = finished ? 0 : (S.xcounts ? S.xcounts[(int64_t)S.it * S.n_frames + f] : local);
+            used = P.used[f];
         }
-        int count = 0, limit = 0, last = 0;
-        if (alive > 0 && used < S.max_samples) {
-            const int q = S.rays_per_frame / alive;
-            limit = q < 64 ? q : 64;
-            if (limit < S.min_samples) limit = S.min_samples;
-            used += limit;
-            last = used >= S.max_samples ? 1 : 0;
-            count = alive;
-        }
-        N.count[f] = count; N.limit[f] = limit; N.last[f] = last; N.used[f] = used;
-        N.slot_base[f] = slots; N.samp_bound[f] = count * limit;
-        N.next[f] = 0;
-        slots = (slots + count + kSlotAlign - 1) & ~(kSlotAlign - 1);
-        samples += (long long)count * limit;
-        alive_total += count;
     }
-    N.total_slots = slots;
-    (void)samples;
-    N.sample_base = S.it < 0 ? 0 : S.plans[S.it].sample_base + S.plans[S.it].total_samples;
-    N.total_samples = 0;
-    N.done = alive_total == 0 ? 1 : 0;
-    S.host[0] = alive_total;                // rays alive entering iteration it + 1: an upper bound for every later one
-    S.host[1] = N.done;
-    __threadfence_system();
-    __hip_atomic_store(&S.host[2], S.seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+    int count = 0, gcount = 0, limit = 0, last = 0;
+    if (global > 0 && used < S.max_samples) {
+        const long long n_total = S.global_rays > 0 ? S.global_rays : S.rays_per_frame;
+        const long long q = n_total / global;
+        limit = q < 64 ? (int)q : 64;
+        if (limit < S.min_samples) limit = S.min_samples;
+        used += limit;
+        last = used >= S.max_samples ? 1 : 0;
+        count = local;
+        gcount = (int)(global < 0x7fffffffll ? global : 0x7fffffffll);
+    }
+    // slot ranges: exclusive prefix sum of the counts rounded up to kSlotAlign
+    const int padded = (count + kSlotAlign - 1) & ~(kSlotAlign - 1);
+    int incl = padded;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+        const int v = __shfl_up(incl, off, 64);
+        if (f >= off) incl += v;
+    }
+    long long alive_here = count, alive_all = gcount;
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) {
+        alive_here += __shfl_xor(alive_here, off, 64);
+        alive_all += __shfl_xor(alive_all, off, 64);
+    }
+    const int total_slots = __shfl(incl, 63, 64);
+    N.count[f] = count; N.gcount[f] = gcount; N.limit[f] = limit; N.last[f] = last; N.used[f] = used;
+    N.slot_base[f] = incl - padded; N.samp_bound[f] = count * limit;
+    N.next[f] = 0;
+    if (f == 0) {
+        N.total_slots = total_slots;
+        N.sample_base = S.it < 0 ? 0 : S.plans[S.it].sample_base + S.plans[S.it].total_samples;
+        N.total_samples = 0;
+        N.done = alive_all == 0 ? 1 : 0;
+        S.host[0] = alive_here;                 // rays alive entering iteration it + 1: an upper bound for every later one
+        S.host[1] = N.done;
+        if (S.host_iter) {
+            S.host_iter[3 * (S.it + 1)] = alive_here;
+            S.host_iter[3 * (S.it + 1) + 1] = N.done;
+        }
+        __threadfence_system();
+        __hip_atomic_store(&S.host[2], S.seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+        if (S.host_iter) __hip_atomic_store(&S.host_iter[3 * (S.it + 1) + 2], S.seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
 }
 
 // The plan of iteration 0.  The launch also brings the call's lattice table (256 floats the host wrote behind the
@@ -207,7 +247,7 @@ __global__ void frame_init_kernel(ScheduleArgs S, float *__restrict__ lattice_de
         const float *src = reinterpret_cast<const float *>(S.host + kHostLatticeWord);
         for (int i = threadIdx.x; i < 256; i += blockDim.x) lattice_dev[i] = src[i];
     }
-    if (threadIdx.x == 0) make_next_plan(S);
+    if (threadIdx.x < 64) make_next_plan(S);        // the first wave (launched with exactly one)
 }
 
 struct MarchArgs {
@@ -432,12 +472,24 @@ __global__ __launch_bounds__(kCompositeThreads) void frame_composite_kernel(
     }
 }
 
-// One thread turns the survivor counts of iteration `it` into the plan of iteration it + 1.  (Folding this into the
+// One wave turns the survivor counts of iteration `it` into the plan of iteration it + 1.  (Folding this into the
 // compositing kernel's last workgroup was tried: the system-scope publish inside that kernel cost more than this
 // launch -- 24 us instead of 14 + 5 per iteration.)
-__global__ void frame_schedule_kernel(ScheduleArgs S)
+__global__ __launch_bounds__(64) void frame_schedule_kernel(ScheduleArgs S)
 {
-    if (threadIdx.x == 0) make_next_plan(S);
+    make_next_plan(S);
+}
+
+// Sharded frames: this process's survivors of iteration `it`, per frame, as the int64 row the exchange step sums over
+// the processes (ced_shard_exchange.reduce) before frame_schedule_kernel reads it.
+__global__ __launch_bounds__(64) void frame_pack_counts_kernel(const IterPlan *__restrict__ plan, int n_frames,
+                                                               int64_t *__restrict__ row)
+{
+    const int f = threadIdx.x;
+    if (f >= n_frames) return;
+    const unsigned long long nx = __hip_atomic_load(&plan->next[f], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const bool finished = plan->last[f] || plan->gcount[f] == 0 || plan->count[f] == 0;
+    row[f] = finished ? 0 : (int64_t)(nx & 0xffffffffull);
 }
 
 __global__ __launch_bounds__(256) void frame_finalize_kernel(int64_t n_rays, const float *__restrict__ bkgd,
@@ -912,7 +964,7 @@ static int render_frames_impl(const ced_field_desc *field, int n_frames, int64_t
                               int32_t t_per_ray, const float *frame_times, const float *bkgd, float *rgb, float *opacity,
                               float *depth, void *workspace, int64_t workspace_bytes, int64_t *host_stats,
                               int64_t *total_samples_out, ced_frame_trace *trace, void *field_stream_, void *stream_,
-                              const char *who)
+                              const char *who, const ced_shard_exchange *xch = nullptr)
 {
     hipStream_t stream = (hipStream_t)stream_;
     // Optional separate stream for the field kernel: callers that keep several frames in flight may hand every frame
@@ -948,6 +1000,13 @@ static int render_frames_impl(const ced_field_desc *field, int n_frames, int64_t
     FrameWorkspace W = carve(workspace, n_rays, n_grids, cap, max_iters, res, frame_times != nullptr);
     CED_REQUIRE((int64_t)W.bytes <= workspace_bytes, "%s: workspace too small (%lld < %lld bytes)", who,
                 (long long)workspace_bytes, (long long)W.bytes);
+    if (xch) {
+        CED_REQUIRE(xch->reduce && xch->counts && xch->global_rays_per_frame >= rays_per_frame &&
+                        xch->global_rays_per_frame < (1ll << 31),
+                    "%s: bad ced_shard_exchange (reduce / counts NULL, or global_rays_per_frame < rays_per_frame)", who);
+        CED_REQUIRE(!field_stream_ || field_stream_ == stream_, "%s: a sharded call takes no separate field stream", who);
+    }
+    long long *const host_iter = xch ? (long long *)host_stats + kHostIterWord : nullptr;
     const dim3 blk(256), grd((unsigned)((n_rays + 255) / 256));
 
     if (n_grids == 1)
@@ -975,7 +1034,8 @@ static int render_frames_impl(const ced_field_desc *field, int n_frames, int64_t
     if (use_lattice) build_lattice(near_plane, step_size, reinterpret_cast<float *>(host_stats + kHostLatticeWord));
     hipLaunchKernelGGL(frame_init_kernel, dim3(1), dim3(64), 0, stream,
                        ScheduleArgs{ W.plans, -1, n_frames, (int)rays_per_frame, min_samples, (int)max_samples,
-                                     (long long *)host_stats, seq },
+                                     (long long *)host_stats, seq, xch ? xch->local_rays : nullptr, nullptr,
+                                     xch ? xch->global_rays_per_frame : 0, host_iter },
                        use_lattice ? W.lattice : (float *)nullptr,
                        (unsigned long long *)(trace ? trace->field_stamps : nullptr),
                        (trace && trace->field_stamps) ? (int)trace->capacity : 0);
@@ -996,14 +1056,28 @@ static int render_frames_impl(const ced_field_desc *field, int n_frames, int64_t
         // run-ahead control: the plan of iteration it - run_ahead must have been published (it is published by the
         // schedule launch of iteration it - run_ahead - 1, or by the initial one)
         const int need = it - run_ahead;
-        if (need >= 0) {
-            rc = wait_published(pub + 2, need == 0 ? seq_plan0 : seq_of[need - 1], stream, who);
-            if (rc) return rc;
-        }
-        if (__atomic_load_n(pub + 2, __ATOMIC_ACQUIRE) >= seq_plan0) {       // something of THIS call has been published
-            if (pub[1]) break;                                              // nothing left: stop enqueueing
-            const long long a = pub[0];
-            if (a >= 0 && a < alive_bound) alive_bound = a;
+        if (xch) {
+            // Sharded frames: every process must enqueue the same number of iterations (each holds a collective), so
+            // the loop ends on the plan of iteration `need` -- identical on all processes -- and on nothing later that
+            // happens to have been published already.
+            if (need >= 0) {
+                volatile long long *rec = host_iter + 3 * need;
+                rc = wait_published(rec + 2, need == 0 ? seq_plan0 : seq_of[need - 1], stream, who);
+                if (rc) return rc;
+                if (rec[1]) break;
+                const long long a = rec[0];
+                if (a >= 0 && a < alive_bound) alive_bound = a;
+            }
+        } else {
+            if (need >= 0) {
+                rc = wait_published(pub + 2, need == 0 ? seq_plan0 : seq_of[need - 1], stream, who);
+                if (rc) return rc;
+            }
+            if (__atomic_load_n(pub + 2, __ATOMIC_ACQUIRE) >= seq_plan0) {       // something of THIS call has been published
+                if (pub[1]) break;                                              // nothing left: stop enqueueing
+                const long long a = pub[0];
+                if (a >= 0 && a < alive_bound) alive_bound = a;
+            }
         }
         IterPlan *plan = W.plans + it;
         const int32_t *cur_list = it == 0 ? nullptr : ((it & 1) ? W.alive_a : W.alive_b);
@@ -1055,9 +1129,24 @@ static int render_frames_impl(const ced_field_desc *field, int n_frames, int64_t
         hipLaunchKernelGGL(frame_composite_kernel, dim3((unsigned)cgrid), dim3(kCompositeThreads), 0, stream,
                            plan, n_frames, (int)rays_per_frame, cur_list, next_list, W.packed, W.t0, W.t1, W.sigma, W.rgbs,
                            rgb, opacity, depth, opc_thres);
+        int64_t *xrow = nullptr;
+        if (xch) {
+            // the exchange step: this process's survivors per frame -> summed over the processes, on the stream
+            xrow = xch->counts + (int64_t)it * n_frames;
+            hipLaunchKernelGGL(frame_pack_counts_kernel, dim3(1), dim3(64), 0, stream, plan, n_frames, xrow);
+            rc = check_launch("render_image_test (pack counts)");
+            if (rc) return rc;
+            const int xrc = xch->reduce(xch->user, xrow, n_frames, it, (void *)stream);
+            if (xrc != 0) {
+                set_error("%s: the exchange step of iteration %d failed (code %d)", who, it, xrc);
+                (void)hipStreamSynchronize(stream);
+                return CED_E_LAUNCH;
+            }
+        }
         hipLaunchKernelGGL(frame_schedule_kernel, dim3(1), dim3(64), 0, stream,
                            ScheduleArgs{ W.plans, it, n_frames, (int)rays_per_frame, min_samples, (int)max_samples,
-                                         (long long *)host_stats, seq });
+                                         (long long *)host_stats, seq, xch ? xch->local_rays : nullptr,
+                                         xch ? xch->counts : nullptr, xch ? xch->global_rays_per_frame : 0, host_iter });
         rc = check_launch("render_image_test (composite / schedule)");
         if (rc) return rc;
     }
@@ -1316,6 +1405,36 @@ extern "C" int ced_render_frames_test(const ced_field_desc *field, int32_t n_fra
                                    total_samples_out, trace, field_stream_, stream_, "render_frames_test");
 }
 
+
+extern "C" int32_t ced_render_frames_test_iterations(float cone_angle, int32_t max_samples)
+{
+    if (max_samples < 0) return -1;
+    return ced::max_iterations(max_samples, ced::min_samples_of(cone_angle));
+}
+
+extern "C" int64_t ced_render_frames_test_host_bytes(float cone_angle, int32_t max_samples)
+{
+    if (max_samples < 0) return -1;
+    const int64_t iters = ced::max_iterations(max_samples, ced::min_samples_of(cone_angle));
+    return (ced::kHostIterWord + 3 * (iters + 2)) * (int64_t)sizeof(int64_t);
+}
+
+extern "C" int ced_render_frames_test_sharded(const ced_field_desc *field, int32_t n_frames, int64_t rays_per_frame,
+                                              const float *rays_o, const float *rays_d, const uint8_t *binaries,
+                                              int32_t n_grids, int32_t res, const float *aabbs, const void *accel,
+                                              float near_plane, float far_plane, float step_size, float cone_angle,
+                                              float early_stop_eps, int32_t max_samples, const float *frame_times,
+                                              const float *bkgd, float *rgb, float *opacity, float *depth, void *workspace,
+                                              int64_t workspace_bytes, int64_t *host_stats, int64_t *total_samples_out,
+                                              ced_frame_trace *trace, void *field_stream_, void *stream_,
+                                              const ced_shard_exchange *exchange)
+{
+    CED_REQUIRE(frame_times != nullptr, "render_frames_test_sharded: null frame_times");
+    return ced::render_frames_impl(field, n_frames, rays_per_frame, rays_o, rays_d, binaries, n_grids, res, aabbs, accel,
+                                   near_plane, far_plane, step_size, cone_angle, early_stop_eps, max_samples, nullptr, 0,
+                                   frame_times, bkgd, rgb, opacity, depth, workspace, workspace_bytes, host_stats,
+                                   total_samples_out, trace, field_stream_, stream_, "render_frames_test_sharded", exchange);
+}
 
 extern "C" int64_t ced_render_image_workspace_bytes(int64_t n_rays, int64_t n_all)
 {

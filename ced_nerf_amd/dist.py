@@ -49,11 +49,18 @@ class ShardedRenderer:
 
     render_fn(rays_o [n,3], rays_d [n,3], timestamps) -> (rgb [n,3], opacity [n,1], depth [n,1], n_samples)
     defaults to the HIP `render_image_test`; tests inject a CPU renderer to exercise the
-    sharding / gather / un-permute logic over gloo."""
+    sharding / gather / un-permute logic over gloo.
+
+    Several ranks: a UNIT of the native call is this rank's share of ONE frame, and every frame runs the loop of the
+    whole image -- `N_samples = N_rays // N_alive` (cednerf/utils.py:231-235) over all ranks' rays, the per-iteration
+    survivor counts all-reduced on the rendering stream (ops.ScheduleExchange on `schedule_group`) -- so the gathered
+    frames are bit-identical to the frames one rank renders alone.  The local rays are laid out [F, n_unit, 3]: frame
+    f's share padded to the common size `n_unit` (`local_real[f]` real rays; padding is never alive and its pixels are
+    dropped by the gather)."""
 
     def __init__(self, field, estimator, world: int, rank: int, device, max_samples: int = 1024,
                  render_kwargs: Optional[Dict] = None, render_fn: Optional[Callable] = None,
-                 force_collective: bool = False, tile_order: bool = False, units: int = 1):
+                 force_collective: bool = False, tile_order: bool = False, units: int = 1, schedule_group=None):
         self.field, self.estimator = field, estimator
         self.world, self.rank, self.device = world, rank, device
         self.max_samples = max_samples
@@ -68,15 +75,36 @@ class ShardedRenderer:
         # tile, not a 64-pixel strip: more coherent marching depths and hash cells) and un-permute the pixels
         self.tile_order = tile_order
         self.unpermute = None
-        # units > 1: the F frames handed to set_rays are `units` groups of F // units consecutive frames, and one
-        # native call (ced_render_frames_test) renders this rank's share of all the groups through shared launches
-        # while every group keeps its own render_image_test schedule.  With one GPU and F == units a group is a
-        # frame, so every frame is rendered exactly as if alone -- only with `units` times larger launches.
+        # ONE rank, units > 1: the F frames handed to set_rays are `units` groups of F // units consecutive frames, and
+        # one native call (ced_render_frames_test) renders all the groups through shared launches while every group
+        # keeps its own render_image_test schedule.  With F == units a group is a frame, so every frame is rendered
+        # exactly as if alone -- only with `units` times larger launches.  (Several ranks: a unit is always one frame.)
         self.units = int(units)
-        assert 1 <= self.units <= 8, "units must be 1..8"
+        assert 1 <= self.units <= 64, "units must be 1..64"
+        # the process group whose ranks share the frames (None = the default group); a renderer that runs concurrently
+        # with others (a lane of PipelinedRenderer) needs a group of its own: collectives of one communicator must be
+        # issued in the same order on every rank, and the lanes' threads issue theirs independently
+        self.schedule_group = schedule_group
+        self.exchange = None           # ops.ScheduleExchange of the current image shape
+        self.sharded = False
 
     def _hip_render(self, rays_o, rays_d, timestamps):
         from .utils import Rays, render_frames_test, render_image_test
+        if self.sharded:
+            F = self.shape[0]
+            ts = timestamps.reshape(-1).float()
+            ts = ts.expand(F).contiguous() if ts.numel() == 1 else ts      # one time for all frames, or one per frame
+            if self.exchange is None:
+                from . import ops
+                H, W = self.shape[1], self.shape[2]
+                self.exchange = ops.ScheduleExchange(F, H * W, self.local_real, rays_o.device, self.max_samples,
+                                                     float(self.render_kwargs.get("cone_angle", 0.0)),
+                                                     group=self.schedule_group)
+            rgb, op, dp, totals = render_frames_test(
+                self.max_samples, self.field, self.estimator, Rays(rays_o.view(F, -1, 3), rays_d.view(F, -1, 3)), timestamps=ts,
+                tracer=self.tracer, field_max_workgroups=self.field_max_workgroups, exchange=self.exchange,
+                **self.render_kwargs)
+            return rgb.view(-1, 3), op.view(-1, 1), dp.view(-1, 1), sum(totals)
         if self.units == 1:
             return render_image_test(self.max_samples, self.field, self.estimator, Rays(rays_o, rays_d),
                                      timestamps=timestamps, tracer=self.tracer, field_stream=self.field_stream,
@@ -100,14 +128,11 @@ class ShardedRenderer:
             return
         self.shape = (F, H, W)
         self._ray_index = None
-        if self.units > 1:
-            if F % self.units:
+        self.exchange = None
+        self.sharded = self.world > 1 or self.force_collective
+        if not self.sharded:
+            if self.units > 1 and F % self.units:
                 raise ValueError(f"{F} frames do not split into {self.units} equal groups")
-            ids = tile_cyclic_assignment(F, H, W, self.world)[1][self.rank]
-            per_group = np.bincount(ids // ((F // self.units) * H * W), minlength=self.units)
-            if len(set(per_group.tolist())) != 1 or any(len(s) != len(ids) for s in tile_cyclic_assignment(F, H, W, self.world)[1]):
-                raise ValueError("the ray shards of the frame groups are not of equal size: use units=1 for this image size")
-        if self.world == 1 and not self.force_collective:
             self.n_local = self.n_pad = o.shape[0]
             self.gather_index = None
             if self.tile_order:
@@ -122,21 +147,35 @@ class ShardedRenderer:
                 self.local_o, self.local_d = o.contiguous(), d.contiguous()
                 self.unpermute = None
             return
+        if F > 64:
+            raise ValueError("at most 64 frames per sharded call")
         _, shards = tile_cyclic_assignment(F, H, W, self.world)
-        self.n_pad = max(len(s) for s in shards)
-        mine = shards[self.rank]
-        self.n_local = len(mine)
-        idx = np.concatenate([mine, np.repeat(mine[-1:], self.n_pad - len(mine))]) if len(mine) < self.n_pad else mine
+        n_img = H * W
+        # rank r's share of frame f (tile order), and the common padded size of a share
+        per = [[s[(s >= f * n_img) & (s < (f + 1) * n_img)] for f in range(F)] for s in shards]
+        self.n_unit = max(1, max(len(x) for row in per for x in row))
+        mine = per[self.rank]
+        self.local_real = [len(x) for x in mine]
+        self.n_local = int(sum(self.local_real))
+        self.n_pad = F * self.n_unit
+        self.global_rays = n_img
+
+        def padded(x):      # padding repeats a real ray (any ray of the image if the share is empty): never alive, never kept
+            fill = x[-1:] if len(x) else np.zeros((1,), np.int64)
+            return np.concatenate([x, np.repeat(fill, self.n_unit - len(x))])
+        idx = np.concatenate([padded(x) for x in mine])
         idx_t = torch.from_numpy(idx.astype(np.int64)).to(o.device)
         self._ray_index = idx_t
         self.local_o = o[idx_t].contiguous()
         self.local_d = d[idx_t].contiguous()
         # destination (flat ray id) of every gathered row; padded rows and every rank's trailing count row go to a
         # position outside the image (dropped by the scatter)
-        n_rays = F * H * W
-        dest = np.full((self.world, self.n_pad + 1), n_rays, np.int64)
-        for r, s in enumerate(shards):
-            dest[r, :len(s)] = s
+        n_rays = F * n_img
+        dest = np.full((self.world, F, self.n_unit), n_rays, np.int64)
+        for r in range(self.world):
+            for f in range(F):
+                dest[r, f, :len(per[r][f])] = per[r][f]
+        dest = np.concatenate([dest.reshape(self.world, -1), np.full((self.world, 1), n_rays, np.int64)], axis=1)
         self.gather_index = torch.from_numpy(dest.reshape(-1)).to(o.device)
 
     @torch.no_grad()

@@ -221,18 +221,31 @@ class OccGridEstimator(torch.nn.Module):
         """The brick distance field of `binaries` for the frame renderer (ops.build_occupancy_accel), rebuilt when the
         grid has changed (set_binaries, _update) and kept otherwise: a video renders hundreds of frames per grid."""
         b = self.binaries
-        key = (b.data_ptr(), b._version, str(b.device))
+        # the generation counter is bumped by every writer of `binaries` in this class (set_binaries, _update,
+        # load_state_dict); pointer / version catch in-place writes from outside (binaries.copy_(...)).  A writer
+        # that goes through `.data` must call invalidate_accel() itself.
+        key = (self.__dict__.get("_grid_generation", 0), b.data_ptr(), b._version, str(b.device))
         if getattr(self, "_accel_key", None) != key:
             with torch.cuda.device(b.device):
                 self._accel = ops.build_occupancy_accel(b.contiguous())
             self._accel_key = key
         return self._accel
 
+    def invalidate_accel(self) -> None:
+        """Forget the cached distance fields: the next render rebuilds them from `binaries`."""
+        self.__dict__["_grid_generation"] = self.__dict__.get("_grid_generation", 0) + 1
+        self._accel_key = None
+
     def set_binaries(self, binaries: torch.Tensor, occs: Optional[torch.Tensor] = None) -> None:
         """Load a precomputed grid (e.g. from a checkpoint's 'occupancy_grid' state)."""
         assert binaries.shape == self.binaries.shape, (binaries.shape, self.binaries.shape)
         self.binaries.copy_(binaries.to(self.binaries.device, torch.bool))
         self.occs.copy_(self.binaries.reshape(-1).float() if occs is None else occs.to(self.occs.device))
+        self.invalidate_accel()
+
+    def _load_from_state_dict(self, *args, **kwargs):
+        super()._load_from_state_dict(*args, **kwargs)
+        self.invalidate_accel()
 
     # ---- grid maintenance (SURVEY 8f row 1): nerfacc OccGridEstimator._update & friends, as driven at
     # train_real.py:202-211,324-336.  Index sampling is torch (it is in nerfacc too); the per-sample
@@ -284,7 +297,10 @@ class OccGridEstimator(torch.nn.Module):
             cell_ids = (lvl * self.cells_per_lvl + indices).contiguous()
             ops.occ_ema_update_(self.occs, cell_ids, occ, 1.0, ema_decay)     # occ already holds density * step
         thre = torch.clamp(self.occs[self.occs >= 0].mean(), max=occ_thre)
-        self.binaries = (self.occs > thre).view(self.binaries.shape)
+        # in place (nerfacc rebinds the attribute): the buffer keeps its address, its version counter advances, and
+        # the cached distance fields of the old grid are dropped explicitly
+        self.binaries.copy_((self.occs > thre).view(self.binaries.shape))
+        self.invalidate_accel()
 
     @torch.no_grad()
     def update_every_n_steps(self, step: int, occ_eval_fn: Callable, occ_thre: float = 1e-2, ema_decay: float = 0.95,
@@ -360,6 +376,7 @@ class OccGridEstimator(torch.nn.Module):
             near_planes = near_planes + torch.rand_like(near_planes) * render_step_size
         return near_planes
 
+    @torch.no_grad()
     def march_onepass(self, rays_o, rays_d, near_plane: float, far_plane: float, render_step_size: float,
                       cone_angle: float, capacity: int, near_planes: Optional[torch.Tensor] = None):
         """`march` in one pass into arrays of `capacity` samples (ops.march_all_onepass): for a caller that can bound the
@@ -376,6 +393,7 @@ class OccGridEstimator(torch.nn.Module):
                                      far_plane, render_step_size, cone_angle, capacity, t_sorted=ev[0], t_indices=ev[1],
                                      hits=ev[2])
 
+    @torch.no_grad()
     def sampling(self, rays_o, rays_d, sigma_fn: Optional[Callable] = None, alpha_fn: Optional[Callable] = None,
                  near_plane: float = 0.0, far_plane: float = 1e10, t_min=None, t_max=None,
                  render_step_size: float = 1e-3, early_stop_eps: float = 1e-4, alpha_thre: float = 0.0,

@@ -745,12 +745,64 @@ def sampling_native(desc: _lib.FieldDesc, rays_o, rays_d, packed_info, t_starts,
     return ray_indices, t0, t1
 
 
+class ScheduleExchange:
+    """ced_shard_exchange for frames whose rays are dealt over the ranks of a torch.distributed group: per iteration the
+    library hands the row of per-frame survivor counts to `reduce`, which enqueues an all-reduce(sum) of it on the
+    calling thread's current stream (the stream the native call runs on), so that every rank's scheduling launch sees
+    the image-global N_alive of cednerf/utils.py:231-235.
+
+    One instance per concurrently running native call (a lane of PipelinedRenderer): the per-iteration rows live in a
+    buffer of its own, and with several lanes every lane needs ITS OWN process group -- the lanes' threads issue their
+    collectives independently, and collectives of one communicator must be issued in the same order on every rank.
+
+    global_rays: rays of the whole image; local_rays [n_frames]: the real (unpadded) rays of this rank's share of every
+    frame.  `reduce_fn(tensor)` replaces the all-reduce (tests)."""
+
+    def __init__(self, n_frames: int, global_rays: int, local_rays, device, max_samples: int, cone_angle: float,
+                 group=None, reduce_fn=None):
+        import torch.distributed as dist
+        L = _lib.lib()
+        self.n_frames = int(n_frames)
+        self.iterations = int(L.ced_render_frames_test_iterations(float(cone_angle), int(max_samples)))
+        self.host_words = (int(L.ced_render_frames_test_host_bytes(float(cone_angle), int(max_samples))) + 7) // 8
+        self.counts = torch.zeros((self.iterations + 1, self.n_frames), device=device, dtype=torch.int64)
+        self.local_rays = torch.as_tensor(local_rays, dtype=torch.int32).reshape(-1).to(device).contiguous()
+        assert self.local_rays.numel() == self.n_frames
+        self.group, self.error, self.calls = group, None, 0
+        self._reduce_fn = reduce_fn
+
+        def _cb(user, counts_ptr, n_counts, iteration, stream):
+            try:
+                row = self.counts[iteration]
+                assert row.data_ptr() == counts_ptr and n_counts == self.n_frames
+                cur = torch.cuda.current_stream(row.device)
+                if cur.cuda_stream != (stream or 0):           # not the thread's current stream: make it so
+                    cur = torch.cuda.ExternalStream(stream, device=row.device)
+                with torch.cuda.stream(cur):
+                    if self._reduce_fn is not None:
+                        self._reduce_fn(row)
+                    else:
+                        dist.all_reduce(row, op=dist.ReduceOp.SUM, group=self.group)
+                self.calls += 1
+                return 0
+            except BaseException as e:                         # never let an exception cross the C frame
+                self.error = e
+                return 1
+
+        self._cb = _lib.EXCHANGE_FN(_cb)
+        self.struct = _lib.ShardExchange(int(global_rays), C.c_void_p(self.local_rays.data_ptr()),
+                                         C.c_void_p(self.counts.data_ptr()), self._cb, None)
+
+
 def render_frames_test_native(desc: _lib.FieldDesc, n_frames: int, rays_o, rays_d, binaries, aabbs, near_plane, far_plane,
                               render_step_size, cone_angle, early_stop_eps, max_samples, frame_times, bkgd,
                               tracer: Optional[FrameTracer] = None, field_stream: Optional[torch.cuda.Stream] = None,
-                              accel: Optional[torch.Tensor] = None, max_workgroups: int = 0):
+                              accel: Optional[torch.Tensor] = None, max_workgroups: int = 0,
+                              exchange: Optional[ScheduleExchange] = None):
     """ced_render_frames_test: `n_frames` frames (rays frame-major, [n_frames * rays_per_frame, 3]) through shared
-    launches, every frame on its own schedule.  Returns (rgb [N,3], opacity [N,1], depth [N,1], [total_samples per frame])."""
+    launches, every frame on its own schedule.  Returns (rgb [N,3], opacity [N,1], depth [N,1], [total_samples per frame]).
+    exchange: the frames are this rank's shares of frames sharded over several ranks (ced_render_frames_test_sharded):
+    one image-global schedule per frame."""
     _chk(rays_o, torch.float32, "rays_o"); _chk(rays_d, torch.float32, "rays_d")
     _chk(aabbs, torch.float32, "aabbs"); _chk(frame_times, torch.float32, "frame_times")
     _chk(bkgd, torch.float32, "render_bkgd", allow_none=True)
@@ -765,24 +817,33 @@ def render_frames_test_native(desc: _lib.FieldDesc, n_frames: int, rays_o, rays_
     L = _lib.lib()
     need = int(L.ced_render_frames_test_workspace_bytes(n_frames, n // n_frames, m, res, float(cone_angle), int(max_samples)))
     if need < 0:
-        raise ValueError("render_frames_test: unsupported sizes (1..8 frames)")
+        raise ValueError("render_frames_test: unsupported sizes (1..64 frames)")
+    host_words = 512 if exchange is None else max(512, exchange.host_words)
     key = (dev.index, torch.cuda.current_stream().cuda_stream)
     with _frame_ws_lock:
         ws = _frame_ws.get(key)
-        if ws is None or ws[0].numel() < need:
-            ws = (torch.empty((max(need, 1),), device=dev, dtype=torch.uint8),
-                  ws[1] if ws is not None else torch.zeros((512,), dtype=torch.int64).pin_memory())
+        if ws is None or ws[0].numel() < need or ws[1].numel() < host_words:
+            ws = (ws[0] if ws is not None and ws[0].numel() >= need else torch.empty((max(need, 1),), device=dev, dtype=torch.uint8),
+                  ws[1] if ws is not None and ws[1].numel() >= host_words else torch.zeros((host_words,), dtype=torch.int64).pin_memory())
             _frame_ws[key] = ws
     rgb = torch.empty((n, 3), device=dev, dtype=torch.float32)
     opacity = torch.empty((n, 1), device=dev, dtype=torch.float32)
     depth = torch.empty((n, 1), device=dev, dtype=torch.float32)
     totals = (C.c_int64 * n_frames)()
-    rc = L.ced_render_frames_test(C.byref(_with_workgroups(desc, max_workgroups)), n_frames, n // n_frames, _p(rays_o),
-                                  _p(rays_d), _p(_as_u8(binaries)), m, res, _p(aabbs), _p(accel), float(near_plane), float(far_plane), float(render_step_size),
-                                  float(cone_angle), float(early_stop_eps), int(max_samples), _p(frame_times), _p(bkgd),
-                                  _p(rgb), _p(opacity), _p(depth), _p(ws[0]), ws[0].numel(), C.c_void_p(ws[1].data_ptr()),
-                                  totals, C.byref(tracer.struct) if tracer is not None else None,
-                                  C.c_void_p(field_stream.cuda_stream) if field_stream is not None else None, _stream())
+    args = (C.byref(_with_workgroups(desc, max_workgroups)), n_frames, n // n_frames, _p(rays_o),
+            _p(rays_d), _p(_as_u8(binaries)), m, res, _p(aabbs), _p(accel), float(near_plane), float(far_plane), float(render_step_size),
+            float(cone_angle), float(early_stop_eps), int(max_samples), _p(frame_times), _p(bkgd),
+            _p(rgb), _p(opacity), _p(depth), _p(ws[0]), ws[0].numel(), C.c_void_p(ws[1].data_ptr()),
+            totals, C.byref(tracer.struct) if tracer is not None else None,
+            C.c_void_p(field_stream.cuda_stream) if field_stream is not None else None, _stream())
+    if exchange is None:
+        rc = L.ced_render_frames_test(*args)
+    else:
+        assert exchange.n_frames == n_frames and exchange.counts.device == dev
+        exchange.error = None
+        rc = L.ced_render_frames_test_sharded(*args, C.byref(exchange.struct))
+        if exchange.error is not None:
+            raise exchange.error
     _lib.check(rc, "render_frames_test")
     return rgb, opacity, depth, [int(v) for v in totals]
 

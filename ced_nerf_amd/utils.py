@@ -249,12 +249,15 @@ def render_frames_test(
     tracer=None,
     field_stream=None,
     field_max_workgroups: int = 0,
+    exchange=None,
 ):
     """`render_image_test` for a stack of frames in one native call (ced_render_frames_test): rays.origins / viewdirs
-    are [F, ..., 3] (F <= 8 frames of equal size), timestamps holds F times.  The frames share the launches of an
+    are [F, ..., 3] (F <= 64 frames of equal size), timestamps holds F times.  The frames share the launches of an
     iteration but each keeps its own reference loop, so frame f of the result equals
     `render_image_test(rays[f], timestamps[f])` bit for bit.  Returns (rgb [F,...,3], opacity [F,...,1],
-    depth [F,...,1], [total_samples of every frame])."""
+    depth [F,...,1], [total_samples of every frame]).
+    exchange (ops.ScheduleExchange): rays[f] is this rank's share of frame f, whose other rays other ranks render; the
+    loop of every frame is then the WHOLE image's (N_rays // N_alive over all ranks, cednerf/utils.py:231-235)."""
     if timestamps is None:
         raise NotImplementedError("DNGPradianceField needs timestamps (dnerf path of cednerf/utils.py:186-194)")
     if radiance_field.training:
@@ -270,7 +273,8 @@ def render_frames_test(
     rgb, opacity, depth, totals = ops.render_frames_test_native(
         radiance_field._descriptor(), n_frames, rays_o, rays_d, estimator.binaries, estimator.aabbs.contiguous(),
         near_plane, far_plane, render_step_size, cone_angle, early_stop_eps, max_samples, ts, bk,
-        tracer=tracer, field_stream=field_stream, accel=estimator.occupancy_accel(), max_workgroups=field_max_workgroups)
+        tracer=tracer, field_stream=field_stream, accel=estimator.occupancy_accel(), max_workgroups=field_max_workgroups,
+        exchange=exchange)
     return rgb.view((*shape[:-1], 3)), opacity.view((*shape[:-1], 1)), depth.view((*shape[:-1], 1)), totals
 
 

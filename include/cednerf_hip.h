@@ -415,7 +415,7 @@ int ced_render_image_test(const ced_field_desc *field, int64_t n_rays, const flo
                           int64_t *total_samples_out, ced_frame_trace *trace, void *field_stream, void *stream);
 
 /* Several frames of a video in ONE call: the reference renders them one after another with
- * render_image_test (train_real.py:531-558); here `n_frames` (1..8) frames of `rays_per_frame` rays each share the
+ * render_image_test (train_real.py:531-558); here `n_frames` (1..64) frames of `rays_per_frame` rays each share the
  * launches of an iteration -- one marching, one field and one compositing launch cover the alive rays of all the
  * frames -- while EVERY FRAME KEEPS ITS OWN reference loop: N_samples = clamp(N_rays // N_alive, min, 64) on its own
  * counts, its own `iteration < max_samples` end.  Each frame's pixels and sample count are therefore exactly those of
@@ -433,6 +433,48 @@ int ced_render_frames_test(const ced_field_desc *field, int32_t n_frames, int64_
                            const float *frame_times, const float *bkgd, float *rgb, float *opacity, float *depth,
                            void *workspace, int64_t workspace_bytes, int64_t *host_stats,
                            int64_t *total_samples_out, ced_frame_trace *trace, void *field_stream, void *stream);
+
+/* ---- frames whose rays are sharded over several processes (one process per GPU) ----
+ * The loop of render_image_test is ONE loop per image: N_samples = clamp(N_rays // N_alive, min, 64)
+ * (cednerf/utils.py:231-235) counts the rays of the whole image, and a ray stays alive on `packed_info[:, 1] ==
+ * N_samples` (utils.py:301-306).  When frame f's rays are dealt over several processes, every process must therefore
+ * run the IMAGE's schedule, not one of its own shard: per iteration the processes exchange, per frame, the number of
+ * their rays that survived (one int64 per frame), and the scheduling launch computes N_samples, the last-iteration
+ * flag and the end of the loop from the sums.  Each ray then receives exactly the samples, termination planes and
+ * pixel values it receives when a single process renders the whole image (bit for bit), whatever the sharding.
+ *
+ * The exchange is the caller's (the library links no communication library): `reduce` is called by the rendering
+ * thread once per enqueued iteration, between that iteration's compositing launch and its scheduling launch, and must
+ * ENQUEUE on `stream` an in-place sum over the processes of counts[0 .. n_counts) (device memory, int64; e.g.
+ * ncclAllReduce / torch.distributed.all_reduce on that stream) and return 0, or non-zero to abort the call.  It must
+ * not block on the device.  Every process makes the same number of calls in the same order: the host loop ends on the
+ * plan of a fixed earlier iteration (CED_FRAME_RUN_AHEAD behind), which is identical on all processes, never on
+ * timing.  No kernel of this library waits for another process.
+ *   global_rays_per_frame: N_rays of the whole image; local_rays: DEVICE int32 [n_frames] or NULL -- how many of the
+ *   frame's `rays_per_frame` local slots hold real rays (shards are padded to a common size; padding is never alive);
+ *   counts: DEVICE int64 [(iterations + 1) * n_frames] scratch, iterations = ced_render_frames_test_iterations();
+ *   host_stats must then hold ced_render_frames_test_host_bytes() bytes of pinned memory. */
+typedef int (*ced_exchange_fn)(void *user, int64_t *counts, int32_t n_counts, int32_t iteration, void *stream);
+typedef struct ced_shard_exchange {
+    int64_t global_rays_per_frame;
+    const int32_t *local_rays;
+    int64_t *counts;
+    ced_exchange_fn reduce;
+    void *user;
+} ced_shard_exchange;
+/* most iterations the loop can take (each uses at least min_samples of the max_samples budget) */
+int32_t ced_render_frames_test_iterations(float cone_angle, int32_t max_samples);
+/* pinned bytes `host_stats` needs for a sharded call (per-iteration publication records) */
+int64_t ced_render_frames_test_host_bytes(float cone_angle, int32_t max_samples);
+/* ced_render_frames_test with `exchange` (NULL: identical to ced_render_frames_test). */
+int ced_render_frames_test_sharded(const ced_field_desc *field, int32_t n_frames, int64_t rays_per_frame,
+                                   const float *rays_o, const float *rays_d, const uint8_t *binaries, int32_t n_grids,
+                                   int32_t res, const float *aabbs, const void *accel, float near_plane, float far_plane,
+                                   float render_step_size, float cone_angle, float early_stop_eps, int32_t max_samples,
+                                   const float *frame_times, const float *bkgd, float *rgb, float *opacity, float *depth,
+                                   void *workspace, int64_t workspace_bytes, int64_t *host_stats,
+                                   int64_t *total_samples_out, ced_frame_trace *trace, void *field_stream, void *stream,
+                                   const ced_shard_exchange *exchange);
 
 /* ---- render_image in eval mode: cednerf/utils.py:46-150 (`estimator.sampling` with sigma_fn, then `rendering`) ----
  * The reference evaluates the density of EVERY marched sample (nerfacc OccGridEstimator.sampling ->

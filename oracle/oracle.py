@@ -476,12 +476,19 @@ def render_image(field: OracleField, est: OracleEstimator, rays_o, rays_d, near_
 # render_image_test, cednerf/utils.py:153-318
 def render_image_test(max_samples, field: OracleField, est: OracleEstimator, rays_o, rays_d, near_plane=0.0,
                       far_plane=1e10, render_step_size=1e-3, render_bkgd=None, cone_angle=0.0, alpha_thre=0.0,
-                      early_stop_eps=1e-4, timestamps=None, trace: Optional[List] = None):
+                      early_stop_eps=1e-4, timestamps=None, trace: Optional[List] = None, alive_reduce=None,
+                      n_total: Optional[int] = None, n_real: Optional[int] = None):
+    """alive_reduce / n_total / n_real: the rays are ONE process's share of an image of n_total rays (the first n_real
+    of them real, the rest padding that is never alive); `alive_reduce(n)` returns the number of alive rays summed over
+    the processes.  N_rays and N_alive of utils.py:231-235 are then the whole image's, as when one process renders it."""
     shape = rays_o.shape
     o = _f32(rays_o).reshape(-1, 3); d = _f32(rays_d).reshape(-1, 3)
     n = o.shape[0]
     opacity = np.zeros((n, 1), np.float32); depth = np.zeros((n, 1), np.float32); rgb = np.zeros((n, 3), np.float32)
     ray_mask = np.ones((n,), bool)
+    if n_real is not None:
+        ray_mask[n_real:] = False
+    n_image = n if n_total is None else int(n_total)
     min_samples = 1 if cone_angle == 0 else 4
     iter_samples = total_samples = 0
     near_planes = np.full((n,), near_plane, np.float32)
@@ -491,9 +498,11 @@ def render_image_test(max_samples, field: OracleField, est: OracleEstimator, ray
     opc_thres = np.float32(1 - early_stop_eps)
     while iter_samples < max_samples:
         n_alive = int(ray_mask.sum())
+        if alive_reduce is not None:
+            n_alive = int(alive_reduce(n_alive))
         if n_alive == 0:
             break
-        n_samples = max(min(n // n_alive, 64), min_samples)
+        n_samples = max(min(n_image // n_alive, 64), min_samples)
         iter_samples += n_samples
         tr = traverse_grids(o, d, est.binaries, est.aabbs, near_planes, far_planes, render_step_size, cone_angle,
                             n_samples, True, ray_mask, t_sorted, t_indices, hits)

@@ -50,6 +50,79 @@ def _worker(rank, world, port, out_dir):
     dist.destroy_process_group()
 
 
+def _global_schedule_render_fn(sc, renderer, group=None, local_schedule=False):
+    """render_image_test of the oracle on this rank's shares, one frame after the other, every frame on the schedule
+    of the WHOLE image: the alive count all-reduced over the ranks each iteration (cednerf/utils.py:231-235).
+    local_schedule=True is the non-conforming variant (every shard on a schedule of its own), for contrast."""
+    from oracle import oracle as O
+    cfg = sc["cfg"]
+    f = O.OracleField(sc["params"]); est = O.OracleEstimator(cfg["aabb"], 128, 1, sc["binaries"])
+
+    def reduce(n):
+        t = torch.tensor([n], dtype=torch.int64)
+        dist.all_reduce(t, group=group)
+        return int(t[0])
+
+    def fn(rays_o, rays_d, timestamps):
+        F, n_unit = renderer.shape[0], renderer.n_unit
+        o = rays_o.numpy().reshape(F, n_unit, 3); d = rays_d.numpy().reshape(F, n_unit, 3)
+        outs, total = [], 0
+        for k in range(F):
+            kw = {} if local_schedule else dict(alive_reduce=reduce, n_total=renderer.global_rays)
+            out = O.render_image_test(64, f, est, o[k], d[k], timestamps=timestamps.numpy(), n_real=renderer.local_real[k],
+                                      **kw, **sc["render"])
+            outs.append(out); total += out[3]
+        cat = lambda i: torch.from_numpy(np.concatenate([x[i] for x in outs]))
+        return cat(0), cat(1), cat(2), total
+    return fn
+
+
+def _worker_global_schedule(rank, world, port, out_dir):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    torch.set_num_threads(2)
+    os.environ["OMP_NUM_THREADS"] = "2"
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from ced_nerf_amd.dist import ShardedRenderer
+    a, b = _scene()
+    o = torch.from_numpy(np.stack([a["origins"], b["origins"]])); d = torch.from_numpy(np.stack([a["viewdirs"], b["viewdirs"]]))
+    res = {}
+    for name, local in (("global", False), ("local", True)):
+        r = ShardedRenderer(None, None, world, rank, "cpu")
+        r.render_fn = _global_schedule_render_fn(a, r, local_schedule=local)
+        r.set_rays(o, d)
+        out = r.render(torch.from_numpy(a["timestamps"]))
+        res.update({f"{name}_{k}": out[k].numpy() for k in ("rgb", "opacity", "depth")})
+        res[f"{name}_total"] = out["total_samples"]
+        res["n_unit"], res["local_real"] = r.n_unit, np.asarray(r.local_real)
+    np.savez(os.path.join(out_dir, f"rank{rank}.npz"), **res)
+    dist.destroy_process_group()
+
+
+def test_sharded_render_image_test_runs_the_image_global_schedule(tmp_path):
+    """render_image_test's loop is one loop per IMAGE (N_samples = N_rays // N_alive over all its rays, a ray alive on
+    packed_info[:, 1] == N_samples: cednerf/utils.py:231-235,301-306).  Two ranks, every frame's rays dealt in 8x8 tiles
+    (15 tiles per frame: uneven, padded shares), the alive count all-reduced per iteration: the gathered frames and the
+    sample total are those of one process rendering the whole frames -- bit for bit; shards on schedules of their own
+    (what round 2 did) are not."""
+    from oracle import oracle as O
+    port = _free_port()
+    mp.spawn(_worker_global_schedule, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    a, b = _scene()
+    cfg = a["cfg"]
+    f = O.OracleField(a["params"]); est = O.OracleEstimator(cfg["aabb"], 128, 1, a["binaries"])
+    whole = [O.render_image_test(64, f, est, s["origins"], s["viewdirs"], timestamps=a["timestamps"], **a["render"]) for s in (a, b)]
+    r0 = np.load(os.path.join(tmp_path, "rank0.npz")); r1 = np.load(os.path.join(tmp_path, "rank1.npz"))
+    assert int(r0["n_unit"]) == 512 and sorted(r0["local_real"].tolist() + r1["local_real"].tolist()) == [448, 448, 512, 512]
+    for i, k in enumerate(("rgb", "opacity", "depth")):
+        want = np.stack([w[i] for w in whole])
+        assert np.array_equal(r0[f"global_{k}"], r1[f"global_{k}"])
+        assert np.array_equal(r0[f"global_{k}"].reshape(want.shape), want), k
+    total = sum(w[3] for w in whole)
+    assert int(r0["global_total"]) == int(r1["global_total"]) == total and total > 1000
+    # the contrast: per-shard schedules march other sample sets
+    assert int(r0["local_total"]) != total
+
+
 def test_tile_cyclic_assignment_is_a_balanced_partition():
     from ced_nerf_amd.dist import tile_cyclic_assignment
     for (F, H, W, world) in ((1, 800, 800, 8), (2, 40, 24, 2), (3, 50, 70, 4), (1, 13, 9, 3)):
@@ -63,10 +136,10 @@ def test_tile_cyclic_assignment_is_a_balanced_partition():
     assert [len(s) for s in shards] == [80000] * 8
 
 
-def test_frame_groups_need_equal_ray_shares():
-    """ShardedRenderer(units=U): the frames split into U groups and every rank's share of every group must be the same
-    number of rays (one native call renders them as U equal units); other shapes are refused up front, and the
-    assignment of a shape is computed once."""
+def test_frame_groups_and_padded_frame_shares():
+    """One rank, units=U: the frames split into U equal groups (one native call renders them as U units).  Several
+    ranks: a unit is one rank's share of ONE frame, padded to the largest share; the gather index sends every real
+    row to its pixel and every padding / count row outside the image."""
     from ced_nerf_amd import dist as cdist
     from ced_nerf_amd.dist import ShardedRenderer
     fn = lambda o, d, ts: (torch.zeros(o.shape[0], 3), torch.zeros(o.shape[0], 1), torch.zeros(o.shape[0], 1), 0)
@@ -75,15 +148,19 @@ def test_frame_groups_need_equal_ray_shares():
     with pytest.raises(ValueError):
         r.set_rays(*rays(3, 16, 16))                       # 3 frames do not split into 2 groups
     r.set_rays(*rays(4, 16, 16))
-    assert r.n_local == 4 * 256
-    two = ShardedRenderer(None, None, 2, 1, "cpu", render_fn=fn, units=2)
+    assert r.n_local == 4 * 256 and not r.sharded
+    two = ShardedRenderer(None, None, 2, 1, "cpu", render_fn=fn)
     two.set_rays(*rays(4, 16, 16))                         # 4 tiles per frame, 2 ranks: equal shares
-    assert two.n_local == two.n_pad == 2 * 256
-    odd = ShardedRenderer(None, None, 2, 0, "cpu", render_fn=fn, units=3)
-    with pytest.raises(ValueError):
-        odd.set_rays(*rays(3, 8, 24))                      # 3 tiles per frame over 2 ranks: uneven shares per group
+    assert two.sharded and two.n_unit == 128 and two.local_real == [128] * 4 and two.n_local == 512 and two.n_pad == 512
+    odd = ShardedRenderer(None, None, 2, 0, "cpu", render_fn=fn)
+    odd.set_rays(*rays(3, 8, 24))                          # 3 tiles per frame over 2 ranks: shares of 2 and 1 tiles
+    assert odd.n_unit == 128 and sorted(odd.local_real) == [64, 128, 128] and odd.n_pad == 3 * 128
+    g = odd.gather_index.numpy().reshape(2, 3 * 128 + 1)
+    real = g[g < 3 * 8 * 24]
+    assert np.array_equal(np.sort(real), np.arange(3 * 8 * 24))       # every pixel exactly once
+    assert (g[:, -1] == 3 * 8 * 24).all()                            # the count rows are dropped
     with pytest.raises(AssertionError):
-        ShardedRenderer(None, None, 1, 0, "cpu", render_fn=fn, units=9)
+        ShardedRenderer(None, None, 1, 0, "cpu", render_fn=fn, units=65)
     a = cdist.tile_cyclic_assignment(4, 16, 16, 2)
     assert cdist.tile_cyclic_assignment(4, 16, 16, 2) is a          # cached per shape
 

@@ -2,6 +2,9 @@
 `render_image_test` (cednerf/utils.py:153-318, image-global N_samples schedule) and by the CPU oracle on the same
 rays -- not a subset, not a self-comparison.
 
+  C1  D-NeRF 400x400, RANDOM-INIT field (BASELINE config 1: density ~ e^-1 everywhere, no ray ends early -- the long-ray
+      path: every ray marches its whole budget through the occupied cells)      schedule + counts + pixels bit-exact
+  C2i the same regime at 800x800                        same
   C2  D-NeRF 800x800, fp32 table, exact MLPs            schedule + counts + pixels bit-exact
   C3  HyperNeRF 536x960, -te -ta -df, 2 levels, cone     same
   C4  DyNeRF 1352x1014, 4 levels (one GPU's view)        same
@@ -33,12 +36,12 @@ def N(t):
     return t.detach().cpu().numpy()
 
 
-def _setup(oracle, name, w, h, prec, mlp_half=False, **kw):
+def _setup(oracle, name, w, h, prec, mlp_half=False, regime="trained", **kw):
     from ced_nerf_amd import synthetic as S
     from ced_nerf_amd.model import DNGPradianceField
     from ced_nerf_amd.nerfacc_api import OccGridEstimator
     from ced_nerf_amd.utils import Rays
-    sc = S.make_scene(name, w, h, "trained", **kw)
+    sc = S.make_scene(name, w, h, regime, **kw)
     cfg = sc["cfg"]
     of = oracle.OracleField(sc["params"], mlp_half=mlp_half)
     oest = oracle.OracleEstimator(cfg["aabb"], cfg["grid_resolution"], cfg["grid_levels"], sc["binaries"])
@@ -51,6 +54,8 @@ def _setup(oracle, name, w, h, prec, mlp_half=False, **kw):
 
 
 EXACT = [
+    ("C1", "dnerf", 400, 400, {"regime": "init"}),
+    ("C2i", "dnerf", 800, 800, {"regime": "init"}),
     ("C2", "dnerf", 800, 800, {}),
     ("C3", "hypernerf", 536, 960, {}),
     ("C4", "dynerf", 1352, 1014, {}),

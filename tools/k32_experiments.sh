@@ -18,7 +18,7 @@ build)
 run)
   for v in ${VARIANTS:-base slpfloor k16}; do
     echo "##### variant $v"
-    if [ "$v" = "base" ]; then unset CED_NERF_LIB; else export CED_NERF_LIB=$R/ced_nerf_amd/libcednerf_hip.$v.so; fi
+    if [ "$v" = "base" ]; then unset CED_NERF_LIB; else export CED_NERF_LIB=$R/build/variants/libcednerf_hip.$v.so; fi
     PRECS=f16x2,f16 timeout -k 10 240 python3 $R/tools/debug_half.py 2>&1 | grep -E "^n=" | cut -c1-150 || true
   done
   echo "##### probe"
