@@ -28,6 +28,8 @@ if ROOT not in sys.path:
 ALG_BYTES_PER_SAMPLE_F32 = 1072.0     # 16*8*2*4 B table + 28 B in + 20 B out
 ALG_BYTES_PER_SAMPLE_F16 = 560.0
 ALG_FLOPS_PER_SAMPLE = 38.0e3         # unpadded MLP flops per sample
+ALG_FLOPS_SIGMA_CHAIN = 27.0e3        # of which xyz_wrap 20.9 k + mlp_base 6.1 k (what counts / opacity / depth depend on)
+ALG_FLOPS_HEAD = 11.0e3               # and mlp_head 11.0 k (feeds rgb only)
 PEAK_HBM_GBS = 8000.0                 # MI355X_MICROARCH.md: HBM3E 8 TB/s
 PEAK_F32_MFMA_TFLOPS = 157.3          # MI355X_MICROARCH.md: f32-input MFMA dense peak
 PEAK_F16_MFMA_TFLOPS = 2500.0         # MI355X_MICROARCH.md: f16/bf16 MFMA dense peak
@@ -42,13 +44,16 @@ def parse():
     ap.add_argument("--height", type=int, default=800)
     ap.add_argument("--scene", default="dnerf", choices=["dnerf", "hypernerf", "dynerf"])
     ap.add_argument("--table-dtype", default="f32", choices=["f32", "f16"])
-    ap.add_argument("--also", default="f16x2,f16",
+    ap.add_argument("--also", default="f32,f16x2,f16",
                     help="comma list of further --mlp-precision modes to time briefly after the main measurement "
                          "(reported under other_mlp_precisions; empty string: none)")
-    ap.add_argument("--mlp-precision", default="f32", choices=["f32", "f16x2", "f16"],
-                    help="arithmetic of the three MLPs (include/cednerf_hip.h CED_MLP_*): f32 = exact fp32 MFMA chain, "
-                         "bit-identical to the CPU oracle; f16x2 = split-fp16 MFMA with fp32 accumulation, fp32-grade "
-                         "(<= 1e-4 on pixels, same sample counts); f16 = fp16 operands, the reference's tcnn class")
+    ap.add_argument("--mlp-precision", default="f32+h16x2", choices=["f32+h16x2", "f32", "f16x2", "f16"],
+                    help="arithmetic of the three MLPs (include/cednerf_hip.h CED_MLP_*): f32+h16x2 (default) = the chain "
+                         "that decides sample counts, opacity and depth (xyz_wrap, hash features, mlp_base, exp) exact "
+                         "fp32 MFMA, bit-identical to the CPU oracle, and only mlp_head (rgb) on split-fp16 MFMA with "
+                         "fp32 accumulation: counts / opacity / depth bit-exact, rgb <= 1e-4 (the north-star's bar); "
+                         "f32 = all three MLPs exact (rgb bit-exact too); f16x2 = all on split-fp16 (<= 1e-4 on pixels, "
+                         "counts within 1e-5); f16 = fp16 operands, the reference's tcnn class")
     ap.add_argument("--pmc-json", default=None,
                     help="per-launch HBM traffic of the field kernel from the rocprofv3 --pmc passes (tools/pmc_summary.py)")
     ap.add_argument("--regime", default="trained")
@@ -484,6 +489,7 @@ def main():
         "value": samples_total / dt, "unit": "samples/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": 1e3 * dt / args.steps, "higher_is_better": True, "scaling": args.scaling, "vs_baseline": None,
         "dtype": {"f32": "f32", "f16x2": "f32 (MLP GEMMs: split-fp16 MFMA, 22-bit operands, fp32 accumulate)",
+                  "f32+h16x2": "f32 (sigma chain: exact fp32 MFMA; colour head: split-fp16 MFMA, 22-bit operands, fp32 accumulate)",
                   "f16": "f16 MLP operands, fp32 accumulate; rest f32"}[args.mlp_precision],
         "mlp_precision": args.mlp_precision, "data": "synthetic",
         "rays_per_sec": n_rays_step * args.steps / dt,
@@ -524,7 +530,7 @@ def main():
         tflops = samples_per_launch * ALG_FLOPS_PER_SAMPLE / (avg_ms * 1e-3) / 1e12
         gbs = samples_per_launch * (ALG_BYTES_PER_SAMPLE_F16 if fp16 else ALG_BYTES_PER_SAMPLE_F32) / (avg_ms * 1e-3) / 1e9
         traffic, traffic_source = None, None
-        exact_kernel = args.mlp_precision == "f32"
+        exact_kernel = args.mlp_precision in ("f32", "f32+h16x2")
         pmc_json = args.pmc_json
         if pmc_json is None:       # the newest committed PMC passes of this workload (profiles/rNN_final_<mode>_pmc.json)
             import glob
@@ -544,7 +550,8 @@ def main():
         # matrix-bound (fp32 MFMA peak).  f16x2 / f16: the GEMMs shrink to a few % of the f16 MFMA peak and the
         # kernel is bound by the hash lookup (SURVEY 8d algorithmic bytes per sample against HBM peak -- the
         # north-star's "HBM roofline on the hash lookup"); the other bound is reported beside it.
-        exact = args.mlp_precision == "f32"
+        exact = args.mlp_precision in ("f32", "f32+h16x2")
+        mixed = args.mlp_precision == "f32+h16x2"
         mfma_peak = PEAK_F32_MFMA_TFLOPS if exact else PEAK_F16_MFMA_TFLOPS
         alg_bytes = ALG_BYTES_PER_SAMPLE_F16 if fp16 else ALG_BYTES_PER_SAMPLE_F32
         kname = "field_kernel" if exact else "field_half_kernel"
@@ -553,7 +560,9 @@ def main():
                   "avg_launch_ms_raw": raw_dev_ms if raw_dev_ms is not None else raw_avg_ms,
                   "timing": "device stamps" if avg_ms is not avg_events_ms else "hip events",
                   "hip_events": {"avg_launch_ms": avg_events_ms, "avg_launch_ms_raw": raw_avg_ms,
-                                 "frac": (samples_per_launch * (ALG_FLOPS_PER_SAMPLE / 1e12 / PEAK_F32_MFMA_TFLOPS if args.mlp_precision == "f32"
+                                 "frac": (samples_per_launch * ((ALG_FLOPS_SIGMA_CHAIN / PEAK_F32_MFMA_TFLOPS + 3.0 * ALG_FLOPS_HEAD / PEAK_F16_MFMA_TFLOPS) / 1e12
+                                                                if args.mlp_precision == "f32+h16x2" else
+                                                                ALG_FLOPS_PER_SAMPLE / 1e12 / PEAK_F32_MFMA_TFLOPS if args.mlp_precision == "f32"
                                                                 else (ALG_BYTES_PER_SAMPLE_F16 if fp16 else ALG_BYTES_PER_SAMPLE_F32) / 1e9 / PEAK_HBM_GBS)
                                           / (avg_events_ms * 1e-3))},
                   "field_busy_over_wall": (busy_dev_ms if busy_dev_ms is not None else busy_ms) / max(span_ms, 1e-9),
@@ -573,17 +582,36 @@ def main():
         if single_field is not None and single_field["launches"] > 0:
             s_ms = single_field["ms"] / single_field["launches"]
             s_spl = single_field["units"] / single_field["launches"]
-            s_tf = s_spl * ALG_FLOPS_PER_SAMPLE / (s_ms * 1e-3) / 1e12
+            s_tf = s_spl * (ALG_FLOPS_SIGMA_CHAIN if mixed else ALG_FLOPS_PER_SAMPLE) / (s_ms * 1e-3) / 1e12
+            s_tf16 = s_spl * 3.0 * ALG_FLOPS_HEAD / (s_ms * 1e-3) / 1e12 if mixed else 0.0
             s_gbs = s_spl * alg_bytes / (s_ms * 1e-3) / 1e9
             line["roofline_single_frame"] = (
-                {"bound": "mfma", "achieved": s_tf, "peak": mfma_peak, "unit": "TFLOP/s", "frac": s_tf / mfma_peak} if exact else
+                {"bound": "mfma", "achieved": s_tf, "peak": mfma_peak, "unit": "TFLOP/s",
+                 "frac": s_tf / mfma_peak + s_tf16 / PEAK_F16_MFMA_TFLOPS} if exact else
                 {"bound": "hbm", "achieved": s_gbs, "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": s_gbs / PEAK_HBM_GBS})
             line["roofline_single_frame"].update({"avg_launch_ms": s_ms, "launches": single_field["launches"]})
+        if mixed:
+            # FLOPs by MFMA class: the sigma chain on the fp32-input MFMA (157.3 TF dense), the colour head on the fp16
+            # MFMA (2.5 PF dense; three fp16 product blocks per algorithmic one).  `frac` = the share of the launch
+            # time the two matrix pipes need at their peaks -- f16 FLOPs are never priced at the fp32 peak.
+            tf32 = samples_per_launch * ALG_FLOPS_SIGMA_CHAIN / (avg_ms * 1e-3) / 1e12
+            tf16 = samples_per_launch * 3.0 * ALG_FLOPS_HEAD / (avg_ms * 1e-3) / 1e12
+            r_mfma.update({"achieved": tf32, "peak": PEAK_F32_MFMA_TFLOPS, "frac": tf32 / PEAK_F32_MFMA_TFLOPS + tf16 / PEAK_F16_MFMA_TFLOPS,
+                           "alg_flops_per_sample": ALG_FLOPS_SIGMA_CHAIN,
+                           "mfma_classes": {
+                               "f32": {"alg_flops_per_sample": ALG_FLOPS_SIGMA_CHAIN, "achieved": tf32, "peak": PEAK_F32_MFMA_TFLOPS,
+                                       "unit": "TFLOP/s", "frac": tf32 / PEAK_F32_MFMA_TFLOPS},
+                               "f16": {"alg_flops_per_sample": ALG_FLOPS_HEAD, "issued_flops_per_sample": 3.0 * ALG_FLOPS_HEAD,
+                                       "achieved": tf16, "peak": PEAK_F16_MFMA_TFLOPS, "unit": "TFLOP/s",
+                                       "frac": tf16 / PEAK_F16_MFMA_TFLOPS}},
+                           "hash_lookup_hbm_frac": samples_per_launch * 1024.0 / (avg_ms * 1e-3) / 1e9 / PEAK_HBM_GBS})
         line["roofline"] = dict(r_mfma if exact else r_hbm, **common)
         line["roofline_hbm" if exact else "roofline_mfma"] = r_hbm if exact else r_mfma
         line["kernel_ms_per_step"] = {k: v["ms"] / min(args.steps, 24) for k, v in prof.items()}
     if others:
-        notes = {"f16x2": "split-fp16 MFMA MLPs, fp32 accumulate: pixels within 1e-4 of the oracle, sample count within 1e-5 "
+        notes = {"f32+h16x2": "sigma chain exact (counts / opacity / depth bit-identical to the oracle), colour head on split-fp16 "
+                              "MFMA: rgb <= 1e-4",
+                 "f16x2": "split-fp16 MFMA MLPs, fp32 accumulate: pixels within 1e-4 of the oracle, sample count within 1e-5 "
                           "relative (early-stop decisions at rounding distance from the threshold may flip)",
                  "f16": "fp16-operand MLPs (the reference's tcnn class; BASELINE config 5 with --table-dtype f16): parity "
                         "against the oracle's fp16-operand mode, tolerance in tests/test_gpu_parity.py",

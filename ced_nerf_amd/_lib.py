@@ -13,10 +13,11 @@ from typing import List, Optional
 _PKG = os.path.dirname(os.path.abspath(__file__))
 _ROOT = os.path.dirname(_PKG)
 LIB_PATH = os.environ.get("CED_NERF_LIB", os.path.join(_PKG, "libcednerf_hip.so"))
-SOURCES = ["runtime.hip", "march.hip", "composite.hip", "field.hip", "field_half.hip", "frame.hip", "occgrid.hip",
+SOURCES = ["runtime.hip", "march.hip", "composite.hip", "field.hip", "field_half.hip", "field_mixed.hip", "frame.hip", "occgrid.hip",
            "raygen.hip", "wgrad.hip", "pixels.hip", "accel.hip", "linear.hip", "mlp.hip"]
-MLP_F32, MLP_F16X2, MLP_F16 = 0, 1, 2          # ced_field_desc.mlp_precision
-MLP_PRECISIONS = {"f32": MLP_F32, "f16x2": MLP_F16X2, "f16": MLP_F16}
+MLP_F32, MLP_F16X2, MLP_F16, MLP_F32_HEAD16X2 = 0, 1, 2, 3          # ced_field_desc.mlp_precision
+# "f32+h16x2": sigma chain exact fp32 (counts / opacity / depth bit-identical to "f32"), colour head on split-fp16 MFMAs
+MLP_PRECISIONS = {"f32": MLP_F32, "f16x2": MLP_F16X2, "f16": MLP_F16, "f32+h16x2": MLP_F32_HEAD16X2}
 # -fno-slp-vectorize: the SLP vectoriser forms packed-fp32 instructions with an op_sel swizzle (v_pk_mul_f32 ...
 # op_sel:[0,1]); on gfx950 that form reads its swizzled operand as zero while another wave of the SIMD runs
 # v_mfma_f32_16x16x32_f16 (tools/probes/pk_opsel_mfma.hip).  tools/isa_lint.py checks the built library.
@@ -77,6 +78,7 @@ PROTOTYPES = {
     "ced_pack_field_weights": (C.c_int, [C.c_int, C.c_int] + [_vp] * 10),
     "ced_packed_weight_words": (_i64, [C.c_int, C.c_int, C.c_int]),
     "ced_pack_field_weights_half": (C.c_int, [C.c_int, C.c_int, C.c_int] + [_vp] * 10),
+    "ced_pack_field_weights_mixed": (C.c_int, [C.c_int, C.c_int] + [_vp] * 10),
     "ced_ray_aabb_intersect": (C.c_int, [_i64, _vp, _vp, _i32, _vp, _f, _f, _f, _vp, _vp, _vp, _vp]),
     "ced_traverse_grids": (C.c_int, [_i64, _vp, _vp, _vp, _i32, _i32, _vp, _vp, _vp, _f, _f, _i32, _vp, _vp, _vp, _vp,
                                      _i32, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
@@ -120,6 +122,7 @@ PROTOTYPES = {
     "ced_render_frames_test": (C.c_int, [C.POINTER(FieldDesc), _i32, _i64, _vp, _vp, _vp, _i32, _i32, _vp, _vp, _f, _f, _f, _f,
                                          _f, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _vp, C.POINTER(_i64),
                                          C.POINTER(FrameTrace), _vp, _vp]),
+    "ced_render_frames_test_sharded_workspace_bytes": (_i64, [_i32, _i64, _i64, _i32, _i32, _f, _i32]),
     "ced_render_frames_test_iterations": (_i32, [_f, _i32]),
     "ced_render_frames_test_host_bytes": (_i64, [_f, _i32]),
     "ced_render_frames_test_sharded": (C.c_int, [C.POINTER(FieldDesc), _i32, _i64, _vp, _vp, _vp, _i32, _i32, _vp, _vp, _f, _f, _f,
@@ -157,6 +160,10 @@ def build(force: bool = False, verbose: bool = False, extra_flags: Optional[List
     srcs = [os.path.join(_PKG, "csrc", s) for s in SOURCES]
     hipcc = os.environ.get("HIPCC", "hipcc")
     flags = [f for f in HIPCC_FLAGS if f != "-shared"] + list(extra_flags or [])
+    if os.environ.get("CED_HALF_MFMA_K32", "0") == "1":
+        # opt-in: the half-precision MLP blocks on v_mfma_f32_16x16x32_f16 (+11 % in f16x2).  Only for processes in
+        # which no foreign kernel (torch, RCCL) can be co-resident with a field kernel: field_half_device.hpp, mfma_k32
+        flags.append("-DCED_HALF_MFMA_K32")
     obj_dir = os.path.join(_ROOT, "build", "obj")
     os.makedirs(obj_dir, exist_ok=True)
     stamp = os.path.join(obj_dir, "flags.txt")

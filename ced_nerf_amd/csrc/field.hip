@@ -19,428 +19,17 @@
 // summation order intact.  The hash gather lives in the same geometry: lane group g owns levels
 // 4i + 2(g&1) + (g>>1), i = 0..3, of its 16 samples (128 gathers per sample spread over 4 lanes) and one
 // v_permlane16_swap per level pair puts the features in operand order.
+#include <atomic>
 #include <cstdlib>
 #include <cstring>
 
 #include "ced_common.hpp"
 #include "field_args.hpp"
 #include "field_device.hpp"
+#include "field_kernel.hpp"
 
 namespace ced {
 
-
-// ---- packed weight blob: layer l stored as [nb][ks4][lane 64][4] floats ----------------------
-struct LayerShape { int nb; int ks; };
-__host__ __device__ constexpr int ks4_of(int ks) { return (ks + 3) / 4; }
-__host__ __device__ constexpr int layer_floats(int nb, int ks) { return nb * ks4_of(ks) * 256; }
-
-// Output-row placement of mlp_base's last layer: accumulator row p = 4g + r (lane group g, register r)
-// holds output neuron base_out_neuron(p).  Neuron 0 is the raw density, neuron n >= 1 is geometry feature
-// n - 1 = input 3 + n of mlp_head (model.py:455), which must sit where k-step r, lane group g reads it.
-__host__ __device__ constexpr int base_out_neuron(int p)
-{
-    const int g = p >> 2, r = p & 3;
-    return r > 0 ? (4 * r + g - 3) : (g < 3 ? 13 + g : 0);
-}
-
-template <bool TE> struct Blob {
-    static constexpr int KS_B0 = TE ? 11 : 8;
-    static constexpr int M0 = 0;
-    static constexpr int M1 = M0 + layer_floats(4, 8);
-    static constexpr int M2 = M1 + layer_floats(4, 16);
-    static constexpr int M3 = M2 + layer_floats(4, 16);
-    static constexpr int B0 = M3 + layer_floats(1, 16);
-    static constexpr int B1 = B0 + layer_floats(4, KS_B0);
-    static constexpr int H0 = B1 + layer_floats(1, 16);
-    static constexpr int H1 = H0 + layer_floats(4, 5);
-    static constexpr int H2 = H1 + layer_floats(4, 16);
-    static constexpr int TOTAL = H2 + layer_floats(1, 16);
-};
-constexpr int kMaxBlobFloats = Blob<true>::TOTAL;
-
-
-// D[j][nb] (16 neurons x 16 samples, neurons 16nb+4g+r on lane group g reg r) =
-//     sum_k W[neuron][k] * B[j][k/4] (k = 4S+g on lane group g), ascending k.
-template <int KS, int NB, int NT>
-__device__ __forceinline__ void mlp_layer(const float *__restrict__ wl, int lane, const float (&B)[NT][16],
-                                          f4 (&D)[NT][4])
-{
-    constexpr int KS4 = ks4_of(KS);
-#pragma unroll
-    for (int nb = 0; nb < NB; ++nb) {
-        f4 acc[NT];
-#pragma unroll
-        for (int j = 0; j < NT; ++j) acc[j] = f4{ 0.0f, 0.0f, 0.0f, 0.0f };
-#pragma unroll
-        for (int q = 0; q < KS4; ++q) {
-            const f4 a = *reinterpret_cast<const f4 *>(wl + ((nb * KS4 + q) * 64 + lane) * 4);
-#pragma unroll
-            for (int s = 0; s < 4; ++s) {
-                if (4 * q + s < KS) {
-#pragma unroll
-                    for (int j = 0; j < NT; ++j)
-                        acc[j] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[s], B[j][4 * q + s], acc[j], 0, 0, 0);
-                }
-            }
-        }
-#pragma unroll
-        for (int j = 0; j < NT; ++j) D[j][nb] = acc[j];
-    }
-}
-
-// ReLU (optional) on the accumulator blocks, which then serve as the next layer's B operand.
-template <int NB, bool RELU, int NT>
-__device__ __forceinline__ void to_operand(const f4 (&D)[NT][4], float (&B)[NT][16])
-{
-#pragma unroll
-    for (int j = 0; j < NT; ++j) {
-#pragma unroll
-        for (int nb = 0; nb < NB; ++nb) {
-            float r[4];
-#pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                float v = D[j][nb][q];
-#ifdef CED_FIELD_SKELETON
-                if constexpr (false) {
-#else
-                if constexpr (RELU) {
-#endif
-                    // ReLU as ONE integer max on the float's bits: non-negative floats order like their bit
-                    // patterns, every negative float (and -0) has the sign bit set, i.e. a negative int.
-                    // Same result as (v > 0 ? v : 0) for every non-NaN v; the float forms (fmax, compare +
-                    // select, med3) all lower to two v_max_f32, the first one only canonicalising.
-                    const int bits = __float_as_int(v);
-                    v = __int_as_float(bits > 0 ? bits : 0);
-                }
-                r[q] = v;
-            }
-            // no lane movement: the host's row placement makes register r of block nb the operand of
-            // k-step 4nb + r (see ced_pack_field_weights)
-#pragma unroll
-            for (int s = 0; s < 4; ++s) B[j][4 * nb + s] = r[s];
-        }
-    }
-}
-
-// NT: 16-sample MFMA column tiles per wave iteration; THREADS: workgroup size (one workgroup per CU)
-template <bool TE, bool F16, bool TEMPORAL, int NT, int THREADS>
-__global__ __launch_bounds__(THREADS) void field_kernel(FieldArgs A)
-{
-    constexpr int FIELD_THREADS = THREADS;
-    constexpr int FIELD_WAVES = THREADS / kWave;
-    constexpr int TILE = 16 * NT;
-    using BL = Blob<TE>;
-    __shared__ __attribute__((aligned(16))) float lds[BL::TOTAL + 8 * CED_MAX_LEVELS];
-    const int tid = threadIdx.x;
-    const int lane = tid & 63;
-    const int wave = tid >> 6;
-    const int g = lane >> 4, c = lane & 15;
-
-    int64_t n_eff = A.n;
-    if (A.n_dev) {
-        const int64_t nd = *A.n_dev;
-        n_eff = nd < n_eff ? nd : n_eff;
-    }
-    // the call's window of persistent per-sample arrays (render_image, frame.hip): ray_idx / t0 / t1 / sigma / rgb
-    // entry s of the call is entry sbase + s of the arrays.  (Kept as an index offset: adding it to the pointers of
-    // the by-value argument block would make the compiler keep the whole block in scratch.)
-    const int64_t sbase = A.base_dev ? *A.base_dev : 0;
-    const int64_t n_tiles = (n_eff + TILE - 1) / TILE;
-    // a workgroup without a tile leaves before staging anything (launches are sized by a host-side upper bound of
-    // the sample count; the exact count comes from device memory)
-    if ((A.spread_tiles ? (int64_t)blockIdx.x * 4 : (int64_t)blockIdx.x * FIELD_WAVES) >= n_tiles) return;
-    if (A.stamp && tid == 0) atomicMin(A.stamp, (unsigned long long)wall_clock64());
-
-    // stage weights + level tables into LDS
-    {
-        const f4 *src = reinterpret_cast<const f4 *>(A.weights);
-        f4 *dst = reinterpret_cast<f4 *>(lds);
-        for (int i = tid; i < BL::TOTAL / 4; i += FIELD_THREADS) dst[i] = src[i];
-        if (tid < CED_MAX_LEVELS) {
-            uint32_t *lt = reinterpret_cast<uint32_t *>(lds + BL::TOTAL);
-            const LevelConst L = make_level(A.scale[tid], A.res[tid], A.offset[tid], A.size[tid], A.hashed[tid],
-                                            EntryBytes<F16, TEMPORAL>::value);
-            store_level(lt + tid * 8, L);
-        }
-    }
-    __syncthreads();
-
-    if (A.stagger > 0) {
-        // Waves w, w+4, w+8 of a workgroup share a SIMD and run the same program: offset their phases so
-        // that their MFMA-dense and VALU-dense stretches interleave instead of colliding.
-        const int slot = __builtin_amdgcn_readfirstlane(wave >> 2);
-        for (int k = 0; k < slot * A.stagger; ++k) __builtin_amdgcn_s_sleep(127);
-    }
-    const float extent[3] = { A.aabb[3] - A.aabb[0], A.aabb[4] - A.aabb[1], A.aabb[5] - A.aabb[2] };
-    // In eval frames every sample carries the same timestamp (cednerf/utils.py:186-193): the two
-    // Frequency features of t that this lane feeds to the motion MLP are computed once.
-    const bool shared_time = A.rays_mode && !A.t_per_ray;
-    float t_feat[2] = { 0.0f, 0.0f };
-    if (shared_time) {
-        const float t_all = A.timestamps[0];
-#pragma unroll
-        for (int S = 6; S < 8; ++S) t_feat[S - 6] = det_sinpi_phase(t_all * (float)(1 << (2 * (S & 1) + (g >> 1))), g & 1);
-    }
-
-    // Tile -> wave mapping: a round of gridDim.x * WAVES tiles is dealt in groups of four consecutive tiles
-    // (the four SIMDs of a CU) across ALL workgroups before any workgroup gets a second group.  The last,
-    // partial round of a launch (a frame's launches are 4-5 rounds long) then leaves every CU with about one
-    // wave per SIMD -- which runs ~2.5x faster than three sharing the MFMA pipe -- instead of a third of the
-    // CUs fully loaded and the rest idle.
-    const int64_t first_tile = A.spread_tiles ? ((int64_t)(wave >> 2) * gridDim.x + blockIdx.x) * 4 + (wave & 3)
-                                              : (int64_t)blockIdx.x * FIELD_WAVES + wave;
-    for (int64_t tile = first_tile; tile < n_tiles; tile += (int64_t)gridDim.x * FIELD_WAVES) {
-        // Re-derive the LDS weight base every tile through an opaque register: the A fragments sit at
-        // tile-invariant addresses and the compiler would otherwise hoist all ~80 ds_read_b128 out of
-        // the persistent loop and park them in scratch.
-        int lds_off = 0;
-        asm volatile("" : "+v"(lds_off));
-        const float *const lw = lds + lds_off;
-        int64_t sidx[NT];
-        int64_t ridx[NT];
-        float px[NT][3], tq[NT];
-        bool any_used = !A.rays_mode;
-#pragma unroll
-        for (int j = 0; j < NT; ++j) {
-            int64_t s = tile * TILE + 16 * j + c;
-            s = s < n_eff ? s : n_eff - 1;
-            sidx[j] = s;
-            if (A.rays_mode) {
-                // a negative ray index marks an unused sample slot (the frame renderer's slot-major sample layout):
-                // it is evaluated on ray 0 at t = 0 and its outputs land in its own, never-read slot
-                const int64_t r_in = A.ray_idx32 ? (int64_t)A.ray_idx32[sbase + s] : A.ray_idx[sbase + s];
-                const bool used = r_in >= 0;
-                const int64_t r = used ? r_in : 0;
-                any_used = any_used || used;
-                ridx[j] = r;
-                const float tm2 = used ? A.t0[sbase + s] + A.t1[sbase + s] : 0.0f;
-#pragma unroll
-                for (int a = 0; a < 3; ++a) px[j][a] = A.rays_o[3 * r + a] + (A.rays_d[3 * r + a] * tm2) / 2.0f;
-                tq[j] = A.t_per_ray ? A.timestamps[r] : A.timestamps[0];
-            } else {
-                ridx[j] = s;
-#pragma unroll
-                for (int a = 0; a < 3; ++a) px[j][a] = A.pos[3 * s + a];
-                tq[j] = A.t[s];
-            }
-        }
-        if (__ballot(any_used) == 0ull) continue;            // a tile of unused slots only (wave-uniform)
-
-        float B[NT][16];
-        f4 D[NT][4];
-
-        // --- tcnn Frequency(4) on (x,y,z,t): feature k = 8*dim + 2*freq + phase, k = 4S+g, i.e. k-step S of lane group g
-        // is dimension S>>1, frequency 2(S&1) + (g>>1), phase g&1.  Lane groups g and g^1 need the same terms in the two
-        // phases, and one evaluation yields both (det_sinpi_both): the even group evaluates one k-step of a pair, the
-        // odd group the other, and a single v_permlane16_swap hands each its partner's half -- swap(p0, p1) leaves the
-        // even group's k-step in the first register and the odd group's in the second, each lane seeing its own phase.
-        // Pairs: (S0 | S2) and (S1 | S3) = x | y at the two frequencies, (S4 | S5) = z at both, (S6 | S7) = t at both. ---
-#pragma unroll
-        for (int j = 0; j < NT; ++j) {
-#ifdef CED_FIELD_SKELETON
-#pragma unroll
-            for (int S = 0; S < 8; ++S) B[j][S] = (S < 6 ? px[j][S >> 1] : tq[j]) * (float)(1 << (2 * (S & 1) + (g >> 1)));
-#elif defined(CED_AB_NO_FREQ_SPLIT)
-#pragma unroll
-            for (int S = 0; S < 8; ++S) {
-                if ((S >> 1) == 3 && shared_time) { B[j][S] = t_feat[S - 6]; continue; }
-                const float v = ((S >> 1) < 3) ? px[j][(S >> 1) < 3 ? (S >> 1) : 0] : tq[j];
-                B[j][S] = det_sinpi_phase(v * (float)(1 << (2 * (S & 1) + (g >> 1))), g & 1);
-            }
-#else
-            const bool odd = (g & 1) != 0;
-            const float sc0 = (float)(1 << (g >> 1)), sc1 = 4.0f * sc0;           // 2^f for the pair's two frequencies
-            const float vxy = odd ? px[j][1] : px[j][0];
-            float p0, p1;
-            det_sinpi_both(vxy * sc0, p0, p1);
-            auto sw = __builtin_amdgcn_permlane16_swap(__float_as_uint(p0), __float_as_uint(p1), false, false);
-            B[j][0] = __uint_as_float(sw[0]); B[j][2] = __uint_as_float(sw[1]);
-            det_sinpi_both(vxy * sc1, p0, p1);
-            sw = __builtin_amdgcn_permlane16_swap(__float_as_uint(p0), __float_as_uint(p1), false, false);
-            B[j][1] = __uint_as_float(sw[0]); B[j][3] = __uint_as_float(sw[1]);
-            const float scz = odd ? sc1 : sc0;
-            det_sinpi_both(px[j][2] * scz, p0, p1);
-            sw = __builtin_amdgcn_permlane16_swap(__float_as_uint(p0), __float_as_uint(p1), false, false);
-            B[j][4] = __uint_as_float(sw[0]); B[j][5] = __uint_as_float(sw[1]);
-            if (shared_time) {                           // eval frames: one timestamp for every sample
-                B[j][6] = t_feat[0];
-                B[j][7] = t_feat[1];
-            } else {
-                det_sinpi_both(tq[j] * scz, p0, p1);
-                sw = __builtin_amdgcn_permlane16_swap(__float_as_uint(p0), __float_as_uint(p1), false, false);
-                B[j][6] = __uint_as_float(sw[0]); B[j][7] = __uint_as_float(sw[1]);
-            }
-#endif
-        }
-        // --- motion MLP 32-64-64-64-(3|6) ---
-        mlp_layer<8, 4, NT>(lw + BL::M0, lane, B, D);
-        to_operand<4, true, NT>(D, B);
-        mlp_layer<16, 4, NT>(lw + BL::M1, lane, B, D);
-        to_operand<4, true, NT>(D, B);
-        mlp_layer<16, 4, NT>(lw + BL::M2, lane, B, D);
-        to_operand<4, true, NT>(D, B);
-        mlp_layer<16, 1, NT>(lw + BL::M3, lane, B, D);
-
-        // --- query_move / normalise / selector (model.py:354-383) ---
-        float xn[NT][3], mnorm[NT];
-        bool sel[NT];
-#pragma unroll
-        for (int j = 0; j < NT; ++j) {
-            float mv[3];
-            bool inside = true;
-#pragma unroll
-            for (int a = 0; a < 3; ++a) {
-                const float off = __shfl(D[j][0][a], c, 64);          // row a lives on lane group 0, reg a
-                float m = off * A.moving_step;
-                if (A.use_div) {
-                    // rows 3,4,5: (g0,r3), (g1,r0), (g1,r1)
-                    constexpr int kFineReg[3] = { 3, 0, 1 };
-                    const float fine = __shfl(D[j][0][kFineReg[a]], (a == 0) ? c : 16 + c, 64);
-                    const float e = det_expf(2.0f * fine);
-                    const float th = 1.0f - 2.0f / (e + 1.0f);
-                    m = m + th * A.moving_step;
-                }
-                mv[a] = m;
-                const float xm = px[j][a] + m;
-                const float x = (xm - A.aabb[a]) / extent[a];
-                inside = inside && (x > 0.0f && x < 1.0f);
-                xn[j][a] = __builtin_fminf(__builtin_fmaxf(x, 0.0f), 1.0f);
-            }
-            sel[j] = inside;
-            mnorm[j] = TE ? __builtin_sqrtf((mv[0] * mv[0] + mv[1] * mv[1]) + mv[2] * mv[2]) : 0.0f;
-        }
-
-        // --- hash gather: this lane's 4 levels for each of its samples, then into operand order ---
-        float R[NT][8];
-        int k_lo[NT];
-        float t_frac[NT];
-#pragma unroll
-        for (int j = 0; j < NT; ++j) {
-            k_lo[j] = 0;
-            t_frac[j] = 0.0f;
-            if constexpr (TEMPORAL) temporal_keyframe(tq[j], k_lo[j], t_frac[j]);
-        }
-        const uint32_t *const ltab = reinterpret_cast<const uint32_t *>(lw + BL::TOTAL);
-#ifdef CED_FIELD_SKELETON   // diagnostic build: MFMA skeleton only (results are meaningless)
-#pragma unroll
-        for (int j = 0; j < NT; ++j)
-#pragma unroll
-            for (int i = 0; i < 8; ++i) R[j][i] = xn[j][i % 3] + (float)i;
-#else
-        // gather slot i of lane group g is level 4i + 2(g&1) + (g>>1): slot i spans levels 4i..4i+3 across the
-        // wave, and when those are all dense or all hashed (wave-uniform, decided on the host) only that index
-        // form is computed.  The level's constants come from LDS here rather than living in registers.
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const LevelConst L = load_level(ltab + (4 * i + 2 * (g & 1) + (g >> 1)) * 8);
-            const int mode = (A.level_mode >> (2 * i)) & 3;
-            if (mode == 1) {
-#pragma unroll
-                for (int j = 0; j < NT; ++j)
-                    hash_level<F16, TEMPORAL, 1>(L, A.table, xn[j], k_lo[j], t_frac[j], R[j][2 * i], R[j][2 * i + 1]);
-            } else if (mode == 2) {
-#pragma unroll
-                for (int j = 0; j < NT; ++j)
-                    hash_level<F16, TEMPORAL, 2>(L, A.table, xn[j], k_lo[j], t_frac[j], R[j][2 * i], R[j][2 * i + 1]);
-            } else {
-#pragma unroll
-                for (int j = 0; j < NT; ++j)
-                    hash_level<F16, TEMPORAL, 0>(L, A.table, xn[j], k_lo[j], t_frac[j], R[j][2 * i], R[j][2 * i + 1]);
-            }
-        }
-#endif
-#pragma unroll
-        for (int j = 0; j < NT; ++j) {
-            // Slot i holds (f0, f1) of level 4i + h on the even lane group 2h (k-step 2i) and of level
-            // 4i + 2 + h on the odd group 2h+1 (k-step 2i+1).  Operand element (k-step S, group g) is
-            // feature g&1 of level 2S + (g>>1): swapping the odd rows of the f0 register with the even rows
-            // of the f1 register leaves k-step 2i in the first and k-step 2i+1 in the second.
-#pragma unroll
-            for (int i = 0; i < 4; ++i) {
-#ifndef CED_FIELD_SKELETON
-                auto sw = __builtin_amdgcn_permlane16_swap(__float_as_uint(R[j][2 * i]), __float_as_uint(R[j][2 * i + 1]), false, false);
-                B[j][2 * i] = __uint_as_float(sw[0]);
-                B[j][2 * i + 1] = __uint_as_float(sw[1]);
-#else
-                B[j][2 * i] = R[j][2 * i];
-                B[j][2 * i + 1] = R[j][2 * i + 1];
-#endif
-            }
-            if (TE) {
-#pragma unroll
-                for (int S = 8; S < 11; ++S) B[j][S] = time_feature(4 * (S - 8) + g, A.time_mode, tq[j], mnorm[j]);
-            }
-        }
-
-        // --- mlp_base (32|41)-64-16; output row placement: see base_out_neuron() ---
-        mlp_layer<BL::KS_B0, 4, NT>(lw + BL::B0, lane, B, D);
-        to_operand<4, true, NT>(D, B);
-        mlp_layer<16, 1, NT>(lw + BL::B1, lane, B, D);
-
-#pragma unroll
-        for (int j = 0; j < NT; ++j) {
-            const int64_t s = tile * TILE + 16 * j + c;
-            float sg = det_expf(D[j][0][0] - 1.0f);           // density = trunc_exp(raw - 1) * selector; raw: group 3, reg 0
-            sg = sel[j] ? sg : 0.0f;
-            if (g == 3 && s < n_eff) A.sigma[sbase + s] = sg;
-            if (A.geo && s < n_eff) {
-#pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const int nidx = base_out_neuron(4 * g + r);
-                    if (nidx >= 1) A.geo[s * 15 + nidx - 1] = D[j][0][r];
-                }
-            }
-        }
-
-        if (A.want_rgb) {
-            // --- head input: [SH(4), geo(15)] (model.py:447-459); k = 4S+g.  The base layer's output rows
-            // were placed so that register r of lane group g is head input 4r + g (r = 1..3) and
-            // 16 + g (r = 0, g < 3); row (g = 3, r = 0) is the raw density, masked out here. ---
-#pragma unroll
-            for (int j = 0; j < NT; ++j) {
-                const float geo_tail = (g == 3) ? 0.0f : D[j][0][0];
-                float dv[3];
-#pragma unroll
-                for (int a = 0; a < 3; ++a)
-                    dv[a] = A.rays_mode ? A.rays_d[3 * ridx[j] + a] : A.dir[3 * sidx[j] + a];
-                const float nrm = __builtin_sqrtf((dv[0] * dv[0] + dv[1] * dv[1]) + dv[2] * dv[2]);
-                // lane group g feeds SH coefficient g: only that one direction component is normalised here
-                // (Y00 const, Y1-1 ~ -y, Y10 ~ z, Y11 ~ -x; tcnn maps the unit vector to [0,1] and back)
-                const float comp = (g == 1) ? dv[1] : (g == 2) ? dv[2] : dv[0];
-                const float u = (comp / nrm + 1.0f) / 2.0f;
-                const float vv = u * 2.0f - 1.0f;
-                const float coef = (g == 2) ? 0.48860251190291987f : -0.48860251190291987f;
-                B[j][0] = (g == 0) ? 0.28209479177387814f : coef * vv;
-                B[j][1] = D[j][0][1];
-                B[j][2] = D[j][0][2];
-                B[j][3] = D[j][0][3];
-                B[j][4] = geo_tail;
-            }
-            mlp_layer<5, 4, NT>(lw + BL::H0, lane, B, D);
-            to_operand<4, true, NT>(D, B);
-            mlp_layer<16, 4, NT>(lw + BL::H1, lane, B, D);
-            to_operand<4, true, NT>(D, B);
-            mlp_layer<16, 1, NT>(lw + BL::H2, lane, B, D);
-#pragma unroll
-            for (int j = 0; j < NT; ++j) {
-                const int64_t s = tile * TILE + 16 * j + c;
-                // the packer put colour channel a on accumulator row 4a = (lane group a, register 0): every lane
-                // evaluates ONE sigmoid (its group's channel) instead of three of which only group 0's were kept
-                const float o1 = 1.0f / (1.0f + det_expf(-D[j][0][0]));
-                // (re-derived from the lane id here rather than kept live across the tile: the kernel sits at the
-                //  168-register limit of three waves per SIMD)
-                int lane_now = (int)threadIdx.x;
-                asm volatile("" : "+v"(lane_now));
-                const int g_now = (lane_now >> 4) & 3;
-                const int64_t s_now = tile * TILE + 16 * j + (lane_now & 15);
-                if (g_now < 3 && s_now < n_eff) A.rgb[3 * (sbase + s_now) + g_now] = o1;
-            }
-        }
-    }
-    // tracing only: every wave stamps its own end (waves of a workgroup finish up to a tile apart; a barrier here
-    // would hold the early ones' registers and cost 3 % of throughput)
-    if (A.stamp && lane == 0) atomicMax(A.stamp + 1, (unsigned long long)wall_clock64());
-}
 
 // ---- standalone hash-grid encode (one lane per point, all levels) ------------------------------
 struct HashArgs {
@@ -668,13 +257,15 @@ __global__ __launch_bounds__(256) void hash_backward_kernel(HashBwdArgs A)
     }
 }
 
-int g_field_stagger = 0;          // field kernel: start-up phase offset between the waves of a SIMD, in s_sleep(127) units
-int g_field_spread_tiles = 1;     // field kernels: deal tiles across all CUs first (ced_set_option)
-bool g_march_early_out = true;    // frame renderer: conservative brick-level early-out (ced_set_option)
+// Diagnostic knobs of ced_set_option: process-wide, read by concurrently rendering threads -> atomics (relaxed: each is
+// an independent launch property; no setting changes a result).
+std::atomic<int> g_field_stagger{ 0 };          // field kernel: start-up phase offset between the waves of a SIMD, in s_sleep(127) units
+std::atomic<int> g_field_spread_tiles{ 1 };     // field kernels: deal tiles across all CUs first
+std::atomic<int> g_march_early_out{ 1 };        // frame renderer: conservative brick-level early-out
 
 // launch-geometry variant of the field kernel (ced_set_option("field_variant", v))
-static int g_hash_grad_form = [] { const char *e = getenv("CED_HASH_GRAD_FORM"); return e ? atoi(e) : 1; }();   // 0: one corner per instruction
-static int g_field_variant = [] { const char *e = getenv("CED_FIELD_VARIANT"); return e ? atoi(e) : 2; }();
+static std::atomic<int> g_hash_grad_form{ []  { const char *e = getenv("CED_HASH_GRAD_FORM"); return e ? atoi(e) : 1; }() };   // 0: one corner per instruction
+static std::atomic<int> g_field_variant{ [] { const char *e = getenv("CED_FIELD_VARIANT"); return e ? atoi(e) : 2; }() };
 
 static int validate_hash(const ced_hash_desc *h, const char *who)
 {
@@ -705,7 +296,7 @@ int launch_field(const ced_field_desc *d, FieldArgs &A, void *stream)
     }
     CED_REQUIRE(d->time_mode >= 0 && d->time_mode <= 2, "field_forward: time_mode=%d", d->time_mode);
     CED_REQUIRE(d->packed_weights != nullptr, "field_forward: null packed_weights");
-    CED_REQUIRE(d->mlp_precision >= CED_MLP_F32 && d->mlp_precision <= CED_MLP_F16, "field_forward: mlp_precision=%d",
+    CED_REQUIRE(d->mlp_precision >= CED_MLP_F32 && d->mlp_precision <= CED_MLP_F32_HEAD16X2, "field_forward: mlp_precision=%d",
                 d->mlp_precision);
     CED_REQUIRE((int64_t)d->packed_floats == ced_packed_weight_words(d->use_div_offsets, d->time_mode, d->mlp_precision),
                 "field_forward: packed_floats=%llu does not match this configuration (mlp_precision %d)",
@@ -739,13 +330,15 @@ int launch_field(const ced_field_desc *d, FieldArgs &A, void *stream)
     A.max_blocks = d->max_workgroups;
     A.stagger = g_field_stagger;
     A.spread_tiles = g_field_spread_tiles;
+    if (d->mlp_precision == CED_MLP_F32_HEAD16X2) return launch_field_mixed(A, d->time_mode, stream);
     if (d->mlp_precision != CED_MLP_F32) {
         // the half kernels gather level 4i + g in slot i: the same slot -> level-range mapping as above
         return launch_field_half(A, d->time_mode, d->mlp_precision, stream);
     }
     // 768 threads (three waves per SIMD, 168 registers) is the default; the time-embedding and temporal-table kernels
     // spill at that cap (76-380 B per lane) and run two waves per SIMD without scratch instead (C3: +1.8 %)
-    const int variant = (g_field_variant == 2 && (d->time_mode || A.temporal)) ? 1 : g_field_variant;
+    const int field_variant = g_field_variant.load(std::memory_order_relaxed);
+    const int variant = (field_variant == 2 && (d->time_mode || A.temporal)) ? 1 : field_variant;
     auto launch = [&](auto kernel, int nt, int threads) {
         const int64_t n_tiles = (A.n + 16 * nt - 1) / (16 * nt);
         const int waves = threads / 64;
@@ -803,6 +396,11 @@ extern "C" int ced_set_option(const char *key, int value)
     if (strcmp(key, "hash_grad_form") == 0) {
         CED_REQUIRE(value == 0 || value == 1, "set_option: hash_grad_form must be 0 or 1");
         ced::g_hash_grad_form = value;
+        return CED_OK;
+    }
+    if (strcmp(key, "mixed_variant") == 0) {
+        CED_REQUIRE(value >= 0 && value <= 2, "set_option: mixed_variant must be 0 (auto), 1 (512 threads) or 2 (768)");
+        ced::set_mixed_variant(value);
         return CED_OK;
     }
     if (strcmp(key, "field_variant") == 0) {

@@ -1,5 +1,6 @@
 // Kernel-argument block of the fused field kernel (field.hip), shared with the frame renderer.
 #pragma once
+#include <atomic>
 #include <cstdint>
 
 #include "../../include/cednerf_hip.h"
@@ -34,8 +35,8 @@ struct FieldArgs {
     uint32_t res[CED_MAX_LEVELS], offset[CED_MAX_LEVELS], size[CED_MAX_LEVELS], hashed[CED_MAX_LEVELS];
 };
 
-extern bool g_march_early_out;
-extern int g_field_spread_tiles;
+extern std::atomic<int> g_march_early_out;
+extern std::atomic<int> g_field_spread_tiles;
 constexpr int kFieldBlocksDefault = 256;      // one persistent workgroup per CU
 
 // Fills the field/hash parts of A from the descriptor, validates, and launches on `stream`.
@@ -43,5 +44,8 @@ int launch_field(const ced_field_desc *d, FieldArgs &A, void *stream);
 // field_half.hip: the f16x2 / f16 MLP variants (A already filled by launch_field)
 int launch_field_half(FieldArgs &A, int time_mode, int precision, void *stream);
 void set_half_variant(int v);
+// field_mixed.hip: exact sigma chain + split-fp16 colour head (CED_MLP_F32_HEAD16X2)
+int launch_field_mixed(FieldArgs &A, int time_mode, void *stream);
+void set_mixed_variant(int v);
 
 }  // namespace ced

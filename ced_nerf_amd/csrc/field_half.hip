@@ -21,6 +21,7 @@
 // inputs are laid out likewise: lane group g computes the eight Frequency features of dimension g,
 // gathers hash levels {g, 4+g, 8+g, 12+g} (input columns are permuted on the host to match), and the
 // last layer of mlp_base is packed so that a lane's four outputs are its own mlp_head inputs.
+#include <atomic>
 #include <cstdlib>
 #include <cstring>
 
@@ -328,7 +329,7 @@ void pack_half_layer(const float *w, int n_out, int n_in, int nb, int ks, int fr
     }
 }
 
-static int g_half_variant = [] { const char *e = getenv("CED_HALF_VARIANT"); return e ? atoi(e) : 0; }();
+static std::atomic<int> g_half_variant{ [] { const char *e = getenv("CED_HALF_VARIANT"); return e ? atoi(e) : 0; }() };
 void set_half_variant(int v) { g_half_variant = v; }
 
 int launch_field_half(FieldArgs &A, int time_mode, int precision, void *stream)
@@ -353,14 +354,15 @@ int launch_field_half(FieldArgs &A, int time_mode, int precision, void *stream)
     case 6: launch(field_half_kernel<false, true, true, SP_, NT_, TH_>, NT_, TH_); break;                       \
     default: launch(field_half_kernel<true, true, true, SP_, NT_, TH_>, NT_, TH_); break;                       \
     }
+    const int half_variant = g_half_variant.load(std::memory_order_relaxed);
     if (precision == CED_MLP_F16X2) {
-        switch (g_half_variant) {
+        switch (half_variant) {
         case 1: CED_HALF_CASE(true, 2, 512) break;
         case 2: CED_HALF_CASE(true, 2, 1024) break;
         default: CED_HALF_CASE(true, 2, 768) break;
         }
     } else {
-        switch (g_half_variant) {
+        switch (half_variant) {
         case 1: CED_HALF_CASE(false, 2, 512) break;
         case 2: CED_HALF_CASE(false, 2, 1024) break;
         default: CED_HALF_CASE(false, 2, 768) break;
@@ -374,7 +376,7 @@ int launch_field_half(FieldArgs &A, int time_mode, int precision, void *stream)
 
 extern "C" int64_t ced_packed_weight_words(int use_div_offsets, int time_mode, int mlp_precision)
 {
-    if (mlp_precision == CED_MLP_F32) return ced_packed_weight_floats(use_div_offsets, time_mode);
+    if (mlp_precision == CED_MLP_F32 || mlp_precision == CED_MLP_F32_HEAD16X2) return ced_packed_weight_floats(use_div_offsets, time_mode);
     if (mlp_precision != CED_MLP_F16X2 && mlp_precision != CED_MLP_F16) return -1;
     const int64_t frags = time_mode ? ced::HalfBlob<true>::FRAGS : ced::HalfBlob<false>::FRAGS;
     return frags * (ced::kFragHalves / 2) * (mlp_precision == CED_MLP_F16X2 ? 2 : 1);

@@ -47,21 +47,23 @@ template <bool SPLIT> __device__ __forceinline__ void to_half8(const float (&v)[
 
 typedef _Float16 h4 __attribute__((ext_vector_type(4)));
 
-// One K = 32 product block of D^T = W * X^T: gfx950's v_mfma_f32_16x16x32_f16.
+// One K = 32 product block of D^T = W * X^T.  Default: TWO v_mfma_f32_16x16x16_f16 over the low / high four halves
+// of each lane's operands.  -DCED_HALF_MFMA_K32 (build-time opt-in, CED_HALF_MFMA_K32=1 in the environment of
+// _lib.build): gfx950's single v_mfma_f32_16x16x32_f16 (f16x2: 4.2 instead of 3.8 Gsamples/s; f16: 5.2 either way).
 //
-// Hazard this file depends on (found in round 2): while a wave of a SIMD executes that MFMA, a
-// packed-fp32 VALU instruction of ANOTHER wave of the SIMD whose op_sel takes the HIGH half of src1 for the low
-// result lane (v_pk_mul_f32 / v_pk_add_f32 ... op_sel:[0,1], v_pk_fma_f32 ... op_sel:[0,1,0]) reads that operand
-// as zero, about once in 1e4 executions (tools/probes/pk_opsel_mfma.hip isolates it: never without the MFMA,
-// never beside v_mfma_f32_16x16x16_f16, never for un-swizzled, op_sel_hi or src0/src2 swizzles).  hipcc's SLP
-// vectoriser emits exactly that form (it did in the hash-coordinate arithmetic of round 1's kernels, which is why
-// they were irreproducible on this MFMA and fine on the 16x16x16 pair), so the library is built with
-// -fno-slp-vectorize and tools/isa_lint.py (tests/test_cabi_cpu.py) rejects any kernel that contains the form.
-// -DCED_HALF_MFMA_K16 rebuilds the block as two v_mfma_f32_16x16x16_f16 over the low / high four halves of each
-// lane's operands (f16x2: 3.8 instead of 4.2 Gsamples/s; f16: 5.2 either way).
+// Why the pair is the default (hazard found in round 2): while a wave of a SIMD executes
+// v_mfma_f32_16x16x32_f16, a packed-fp32 VALU instruction of ANOTHER wave of the SIMD whose op_sel takes the HIGH
+// half of src1 for the low result lane (v_pk_mul_f32 / v_pk_add_f32 ... op_sel:[0,1], v_pk_fma_f32 ... op_sel:[0,1,0])
+// reads that operand as zero, about once in 1e4 executions (tools/probes/pk_opsel_mfma.hip isolates it: never without
+// the MFMA, never beside v_mfma_f32_16x16x16_f16, never for un-swizzled, op_sel_hi or src0/src2 swizzles).  This
+// library is built with -fno-slp-vectorize (hipcc's SLP vectoriser emits that form) and tools/isa_lint.py rejects any
+// kernel of it that contains the form -- but kernels of OTHER code objects (torch element-wise / gather kernels, RCCL)
+// run on other streams beside the field kernels of a pipelined renderer, are compiled with SLP, and cannot be
+// linted here: they would be corrupted silently.  The K = 32 form is therefore only for processes in which nothing
+// foreign can be co-resident with a half-precision field kernel.
 __device__ __forceinline__ f4 mfma_k32(const h8 &a, const h8 &b, f4 c)
 {
-#ifndef CED_HALF_MFMA_K16
+#ifdef CED_HALF_MFMA_K32
     return __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, c, 0, 0, 0);
 #else
     const h4 a0 = { a[0], a[1], a[2], a[3] }, a1 = { a[4], a[5], a[6], a[7] };

@@ -897,6 +897,20 @@ static inline int min_samples_of(float cone_angle) { return cone_angle == 0.0f ?
 // iterations the reference loop can take: each one uses at least min_samples of the max_samples budget
 static inline int max_iterations(int max_samples, int min_samples) { return (max_samples + min_samples - 1) / min_samples; }
 
+// Samples one iteration can march, over all frames of a call.  A frame alone: alive * N_samples with N_samples =
+// clamp(N // alive, min, 64), i.e. at most N * min_samples.  A SHARE of a frame whose loop is the whole image's
+// (ced_shard_exchange): N_samples = N_image // alive_image, and this process's alive rays may be any part of
+// alive_image -- at most min(local rays * 64, N_image) samples (or local rays * min_samples when that clamp binds).
+static inline int64_t sample_capacity(int n_frames, int64_t rays_per_frame, int min_samples, int64_t global_rays)
+{
+    int64_t per = rays_per_frame * min_samples;
+    if (global_rays > rays_per_frame) {
+        const int64_t worst = rays_per_frame * 64 < global_rays ? rays_per_frame * 64 : global_rays;
+        if (worst > per) per = worst;
+    }
+    return per * n_frames;
+}
+
 static FrameWorkspace carve(void *base, int64_t n, int m, int64_t cap, int max_iters, int res, bool per_ray_times = false)
 {
     FrameWorkspace w{};
@@ -995,7 +1009,8 @@ static int render_frames_impl(const ced_field_desc *field, int n_frames, int64_t
                     workspace && host_stats,
                 "%s: null pointer", who);
     const int min_samples = min_samples_of(cone_angle);
-    const int64_t cap = n_rays * min_samples;
+    const int64_t cap = sample_capacity(n_frames, rays_per_frame, min_samples, xch ? xch->global_rays_per_frame : 0);
+    CED_REQUIRE(cap < (1ll << 31) - 64, "%s: too many samples per iteration for 32-bit sample indices", who);
     const int max_iters = max_iterations(max_samples, min_samples);
     FrameWorkspace W = carve(workspace, n_rays, n_grids, cap, max_iters, res, frame_times != nullptr);
     CED_REQUIRE((int64_t)W.bytes <= workspace_bytes, "%s: workspace too small (%lld < %lld bytes)", who,
@@ -1405,6 +1420,19 @@ extern "C" int ced_render_frames_test(const ced_field_desc *field, int32_t n_fra
                                    total_samples_out, trace, field_stream_, stream_, "render_frames_test");
 }
 
+
+extern "C" int64_t ced_render_frames_test_sharded_workspace_bytes(int32_t n_frames, int64_t rays_per_frame,
+                                                                  int64_t global_rays_per_frame, int32_t n_grids,
+                                                                  int32_t res, float cone_angle, int32_t max_samples)
+{
+    if (n_frames < 1 || n_frames > ced::kMaxFrames || rays_per_frame < 0 || global_rays_per_frame < rays_per_frame ||
+        n_grids < 1 || n_grids > ced::kMaxGrids || res < 1 || res > 1024 || max_samples < 0)
+        return -1;
+    const int64_t n_rays = (int64_t)n_frames * rays_per_frame;
+    const int ms = ced::min_samples_of(cone_angle);
+    return (int64_t)ced::carve(nullptr, n_rays, n_grids, ced::sample_capacity(n_frames, rays_per_frame, ms, global_rays_per_frame),
+                               ced::max_iterations(max_samples, ms), res, true).bytes;
+}
 
 extern "C" int32_t ced_render_frames_test_iterations(float cone_angle, int32_t max_samples)
 {

@@ -93,6 +93,13 @@ def pack_field_weights(use_div_offsets: bool, time_mode: int, xyz_wrap, mlp_base
     got = [m.shape for m in mats]
     if got != want:
         raise ValueError(f"weight shapes {got} do not match the DNGPradianceField layout {want}")
+    if mlp_precision == _lib.MLP_F32_HEAD16X2:          # fp32 sigma chain + fp16 fragments of the colour head, fp32-blob sized
+        n = int(L.ced_packed_weight_floats(int(use_div_offsets), int(time_mode)))
+        out = np.zeros((n,), np.float32)
+        rc = L.ced_pack_field_weights_mixed(int(use_div_offsets), int(time_mode),
+                                            *[m.ctypes.data_as(C.c_void_p) for m in mats], out.ctypes.data_as(C.c_void_p))
+        _lib.check(rc, "pack_field_weights_mixed")
+        return out
     if mlp_precision != _lib.MLP_F32:
         n = int(L.ced_packed_weight_words(int(use_div_offsets), int(time_mode), int(mlp_precision)))
         if n <= 0:
@@ -815,7 +822,11 @@ def render_frames_test_native(desc: _lib.FieldDesc, n_frames: int, rays_o, rays_
     assert aabbs.shape == (m, 6)
     dev = rays_o.device
     L = _lib.lib()
-    need = int(L.ced_render_frames_test_workspace_bytes(n_frames, n // n_frames, m, res, float(cone_angle), int(max_samples)))
+    if exchange is None:
+        need = int(L.ced_render_frames_test_workspace_bytes(n_frames, n // n_frames, m, res, float(cone_angle), int(max_samples)))
+    else:
+        need = int(L.ced_render_frames_test_sharded_workspace_bytes(n_frames, n // n_frames, int(exchange.struct.global_rays_per_frame),
+                                                                    m, res, float(cone_angle), int(max_samples)))
     if need < 0:
         raise ValueError("render_frames_test: unsupported sizes (1..64 frames)")
     host_words = 512 if exchange is None else max(512, exchange.host_words)

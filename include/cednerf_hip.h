@@ -96,6 +96,11 @@ int ced_set_option(const char *key, int value);
 #define CED_MLP_F32 0
 #define CED_MLP_F16X2 1
 #define CED_MLP_F16 2
+/*   CED_MLP_F32_HEAD16X2  the chain that decides sample counts, opacity and depth -- xyz_wrap, the hash features,
+ *                  mlp_base, trunc_exp (cednerf/model.py:354-445) -- exactly as CED_MLP_F32, bit-identical to the CPU
+ *                  oracle; only mlp_head (model.py:447-466), which feeds rgb alone, on split-fp16 operands as
+ *                  CED_MLP_F16X2.  sigma, counts, opacity and depth equal the exact mode's bits; rgb within 1e-4. */
+#define CED_MLP_F32_HEAD16X2 3
 
 /* Number of floats in the packed (MFMA-fragment-order) fp32 weight blob. */
 int64_t ced_packed_weight_floats(int use_div_offsets, int time_mode);
@@ -120,6 +125,13 @@ int ced_pack_field_weights_half(int use_div_offsets, int time_mode, int mlp_prec
                                 const float *b_w0, const float *b_w1,
                                 const float *h_w0, const float *h_w1, const float *h_w2,
                                 void *out);
+/* HOST packer for CED_MLP_F32_HEAD16X2: `out` holds ced_packed_weight_floats() floats (the head's region carries fp16
+ * fragments). */
+int ced_pack_field_weights_mixed(int use_div_offsets, int time_mode,
+                                 const float *m_w0, const float *m_w1, const float *m_w2, const float *m_w3,
+                                 const float *b_w0, const float *b_w1,
+                                 const float *h_w0, const float *h_w1, const float *h_w2,
+                                 float *out);
 
 /* nerfacc.ray_aabb_intersect(rays_o, rays_d, aabbs, near_plane, far_plane, miss_value)
  * -- call site cednerf/utils.py:215.  Outputs [n_rays, n_aabbs]. */
@@ -462,6 +474,11 @@ typedef struct ced_shard_exchange {
     ced_exchange_fn reduce;
     void *user;
 } ced_shard_exchange;
+/* device bytes of `workspace` for a sharded call: a share's rays may hold any part of the image's alive rays, so its
+ * sample arrays are sized for min(rays_per_frame * 64, global_rays_per_frame) samples per frame and iteration */
+int64_t ced_render_frames_test_sharded_workspace_bytes(int32_t n_frames, int64_t rays_per_frame,
+                                                       int64_t global_rays_per_frame, int32_t n_grids, int32_t res,
+                                                       float cone_angle, int32_t max_samples);
 /* most iterations the loop can take (each uses at least min_samples of the max_samples budget) */
 int32_t ced_render_frames_test_iterations(float cone_angle, int32_t max_samples);
 /* pinned bytes `host_stats` needs for a sharded call (per-iteration publication records) */

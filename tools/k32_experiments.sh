@@ -12,7 +12,7 @@ R=$(cd "$(dirname "$0")/.." && pwd)
 case "$1" in
 build)
   SRCS="field_half" $R/tools/build_variant.sh slpfloor -fslp-vectorize -DCED_AB_NO_FRACT
-  SRCS="field_half" $R/tools/build_variant.sh k16 -DCED_HALF_MFMA_K16
+  SRCS="field_half field_mixed" $R/tools/build_variant.sh k32 -DCED_HALF_MFMA_K32
   hipcc --offload-arch=gfx950 -O3 -fno-slp-vectorize -o $R/tools/probes/pk_opsel_mfma $R/tools/probes/pk_opsel_mfma.hip
   ;;
 run)
