@@ -330,3 +330,61 @@ def test_built_library_has_no_src1_high_op_sel_packed_fp32():
     n, bad = lint.scan(_lib.build())
     assert n > 100, f"only {n} kernels found in the library"
     assert not bad, f"kernels with a src1-high op_sel packed-fp32 instruction: {sorted(bad)}"
+
+
+def test_reference_checkpoint_layout_round_trip_cpu(tmp_path):
+    """f3 (train_real.py:433-441,524-529), tiny-cuda-nn half: a `model.pth` written in the documented layout hypothesis
+    (tools/write_reference_checkpoint.py: flat `params` per tcnn module, 16-padded row-major matrices, ones-padded inputs)
+    loads into fresh modules with the reference's two load_state_dict calls replaced by load_reference_checkpoint:
+    hash table, motion MLP and mlp_base come back bit for bit; mlp_head's ones-padded bias column is folded into its
+    constant Y00 input (same function: checked on random head inputs); the layout must be named explicitly; a
+    time-embedding checkpoint whose padded mlp_base columns act as a bias is refused."""
+    import subprocess, sys
+    from ced_nerf_amd import checkpoint as CK, synthetic as S
+    from ced_nerf_amd.model import DNGPradianceField
+    from ced_nerf_amd.nerfacc_api import OccGridEstimator
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    path = str(tmp_path / "model.pth")
+    out = subprocess.run([sys.executable, os.path.join(root, "tools", "write_reference_checkpoint.py"), path, "--head-bias"],
+                         capture_output=True, text=True, cwd=root)
+    assert out.returncode == 0, out.stderr[-2000:]
+    ck = torch.load(path)
+    assert set(ck) == {"radiance_field", "occupancy_grid"}
+    assert set(ck["radiance_field"]) == {"aabb", "hash_encoder.params", "xyz_wrap.params", "mlp_base.params", "mlp_head.params",
+                                         "direction_encoding.params"}
+    assert ck["radiance_field"]["mlp_head.params"].numel() == 64 * 32 + 64 * 64 + 16 * 64        # 19 -> 32, 3 -> 16
+    sc = S.make_scene("dnerf", 64, 48, "trained", log2_hashmap_size=15)
+    cfg = sc["cfg"]
+    src = DNGPradianceField.from_params(sc["params"], "cpu")
+    dst = DNGPradianceField(aabb=[0, 0, 0, 1, 1, 1], dst_resolution=cfg["hash_max_res"], log2_hashmap_size=15,
+                            moving_step=cfg["moving_step"], seed=3, **cfg["flags"])
+    est = OccGridEstimator(cfg["aabb"], cfg["grid_resolution"], cfg["grid_levels"])
+    with pytest.raises(ValueError, match="assume_tcnn_layout"):
+        CK.load_reference_checkpoint(path, dst, est)
+    CK.load_reference_checkpoint(path, dst, est, assume_tcnn_layout=CK.TCNN_LAYOUT)
+    assert torch.equal(dst.hash_table, src.hash_table) and torch.equal(dst.aabb, src.aabb)
+    for a, b in zip(list(dst.xyz_wrap) + list(dst.mlp_base) + list(dst.mlp_head)[1:],
+                    list(src.xyz_wrap) + list(src.mlp_base) + list(src.mlp_head)[1:]):
+        assert torch.equal(a, b)
+    assert torch.equal(est.binaries, torch.from_numpy(sc["binaries"])) and est.occs.sum() > 0
+    # the head's first layer: W_file . [x, 1 (ones padding)] == W_loaded . x for inputs whose element 0 is Y00
+    rng = np.random.default_rng(0)
+    x = rng.normal(size=(100, 19)); x[:, 0] = CK.SH_Y00
+    w_file = ck["radiance_field"]["mlp_head.params"][:64 * 32].reshape(64, 32).double().numpy()
+    assert np.abs(w_file[:, 19]).max() > 0.01 and not w_file[:, 20:].any()
+    want = np.concatenate([x, np.ones((100, 13))], axis=1) @ w_file.T
+    got = x @ dst.mlp_head[0].double().numpy().T
+    assert np.abs(got - want).max() <= 1e-6
+    # and back: the inverse map reproduces the file's sigma-chain tensors
+    again = CK.reference_state_from_field(dst)
+    for k in ("hash_encoder.params", "xyz_wrap.params", "mlp_base.params"):
+        assert torch.equal(again[k], ck["radiance_field"][k]), k
+    # time embedding: 41 inputs padded to 48 with ones -- a bias in those columns cannot be expressed
+    te = DNGPradianceField(aabb=[0, 0, 0, 1, 1, 1], log2_hashmap_size=12, dst_resolution=256, use_time_embedding=True, seed=1)
+    sd = CK.reference_state_from_field(te)
+    CK.field_params_from_reference_state(sd, log2_hashmap_size=12, dst_resolution=256, use_time_embedding=True,
+                                         assume_tcnn_layout=CK.TCNN_LAYOUT)
+    sd["mlp_base.params"][41] = 0.25
+    with pytest.raises(NotImplementedError, match="padded"):
+        CK.field_params_from_reference_state(sd, log2_hashmap_size=12, dst_resolution=256, use_time_embedding=True,
+                                             assume_tcnn_layout=CK.TCNN_LAYOUT)

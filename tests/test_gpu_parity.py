@@ -4,6 +4,8 @@ Bars (BASELINE.json north_star): sample indices / counts bit-exact; composited R
 1e-4 abs.  Because the kernels and the oracle share one arithmetic contract, most float outputs
 are in fact compared bit for bit.
 """
+import os
+
 import numpy as np
 import pytest
 import torch
@@ -1406,6 +1408,38 @@ def test_checkpoint_round_trip_renders_the_same_frame(oracle):
     assert got[3] == want[3] and want[3] > 1000
     for a, b in zip(got[:3], want[:3]):
         assert torch.equal(a, b)
+
+
+def test_reference_checkpoint_renders_the_same_frame(oracle, tmp_path):
+    """f3, tiny-cuda-nn half (ced_nerf_amd/checkpoint.py): the synthetic field written as a REFERENCE `model.pth` under
+    the documented tcnn layout hypothesis (flat params, 16-padding, a bias in mlp_head's ones-padded input column), loaded
+    with load_reference_checkpoint into fresh modules built with the reference's constructor flags: sample count,
+    opacity and depth bit-identical (the sigma chain's tensors come back bit for bit), rgb to 1e-5 (the bias folded
+    into the constant Y00 input is the same function in real arithmetic)."""
+    import subprocess, sys
+    from ced_nerf_amd import checkpoint as CK
+    from ced_nerf_amd.model import DNGPradianceField
+    from ced_nerf_amd.nerfacc_api import OccGridEstimator
+    from ced_nerf_amd.utils import render_image_test
+    sc = _scene("dnerf", 64, 48, "trained", log2_hashmap_size=15)
+    of, oest, f, est, rays, rk = _setup(oracle, sc)
+    cfg = sc["cfg"]
+    ts = T(sc["timestamps"])
+    want = render_image_test(1024, f, est, rays, timestamps=ts, **rk)
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    path = str(tmp_path / "model.pth")
+    out = subprocess.run([sys.executable, os.path.join(root, "tools", "write_reference_checkpoint.py"), path, "--head-bias"],
+                         capture_output=True, text=True, cwd=root)
+    assert out.returncode == 0, out.stderr[-2000:]
+    f2 = DNGPradianceField(aabb=cfg["aabb"], dst_resolution=cfg["hash_max_res"], log2_hashmap_size=15,
+                           moving_step=cfg["moving_step"], seed=11, **cfg["flags"]).to(DEV).eval()
+    est2 = OccGridEstimator(cfg["aabb"], cfg["grid_resolution"], cfg["grid_levels"]).to(DEV)
+    f2._descriptor()                                             # packed once with the random weights: must be re-packed
+    CK.load_reference_checkpoint(path, f2, est2, assume_tcnn_layout=CK.TCNN_LAYOUT)
+    got = render_image_test(1024, f2, est2, rays, timestamps=ts, **rk)
+    assert got[3] == want[3] and want[3] > 1000
+    assert torch.equal(got[1], want[1]) and torch.equal(got[2], want[2])
+    assert (got[0] - want[0]).abs().max().item() <= 1e-5
 
 
 def test_scatter_pixels_unpermutes_and_converts(oracle):
