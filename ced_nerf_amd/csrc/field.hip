@@ -262,6 +262,7 @@ __global__ __launch_bounds__(256) void hash_backward_kernel(HashBwdArgs A)
 std::atomic<int> g_field_stagger{ 0 };          // field kernel: start-up phase offset between the waves of a SIMD, in s_sleep(127) units
 std::atomic<int> g_field_spread_tiles{ 1 };     // field kernels: deal tiles across all CUs first
 std::atomic<int> g_march_early_out{ 1 };        // frame renderer: conservative brick-level early-out
+std::atomic<int> g_march_two_pass{ -1 };        // frame renderer: first iteration as culling pass + marching of the rest (-1: when there are several grid levels)
 
 // launch-geometry variant of the field kernel (ced_set_option("field_variant", v))
 static std::atomic<int> g_hash_grad_form{ []  { const char *e = getenv("CED_HASH_GRAD_FORM"); return e ? atoi(e) : 1; }() };   // 0: one corner per instruction
@@ -386,6 +387,11 @@ extern "C" int ced_set_option(const char *key, int value)
     }
     if (strcmp(key, "march_early_out") == 0) {
         ced::g_march_early_out = value != 0;
+        return CED_OK;
+    }
+    if (strcmp(key, "march_two_pass") == 0) {
+        CED_REQUIRE(value >= -1 && value <= 1, "set_option: march_two_pass must be -1 (automatic), 0 or 1");
+        ced::g_march_two_pass = value;
         return CED_OK;
     }
     if (strcmp(key, "half_variant") == 0) {

@@ -23,6 +23,15 @@
 
 #include "march_core.hpp"
 
+// Diagnostic build (-DCED_MARCH_DIAG, tools/march_diag.py): every phase of the walk reports how many lanes of the wave
+// are in it and how long the wave stays in it.  Nothing in the shipped library.
+#if defined(CED_MARCH_DIAG) && defined(__HIP_DEVICE_COMPILE__)
+__device__ void ced_diag_tick(int phase);
+#define CED_DIAG_TICK(p) ced_diag_tick(p)
+#else
+#define CED_DIAG_TICK(p) ((void)0)
+#endif
+
 namespace ced {
 
 constexpr int kBrickShift = 3;                 // kBrick == 8
@@ -193,6 +202,7 @@ CED_HD bool coarse_advance(const AccelSpec &S, int lvl, int res, const float *__
     const float inv_g = 1.0f / g;
     float t = t_from;
     for (int guard = 0; guard < 8192; ++guard) {
+        CED_DIAG_TICK(2);
         int c[3];
 #pragma unroll
         for (int a = 0; a < 3; ++a) c[a] = clampi((int)((o[a] + d[a] * t - ab[a]) * sc[a]), 0, res - 1);
@@ -210,8 +220,11 @@ CED_HD bool coarse_advance(const AccelSpec &S, int lvl, int res, const float *__
 // a frame: most rays miss everything); otherwise only after a stretch of empty cells (later iterations: a live ray
 // stands in or next to occupied cells).  LOOK: cells the exact walk looks ahead (their occupancy bytes are fetched
 // together).  SINGLE: one grid level -- the ray/box interval is recomputed here with the set-up kernel's arithmetic
-// instead of being loaded (ts_row / ti_row / hit_row unused).
-template <int LOOK, bool SINGLE, class Emit>
+// instead of being loaded (ts_row / ti_row / hit_row unused).  PHASED: the exact walk as a looking loop and an emission
+// phase (a frame's first iteration: rays travel to their first occupied cell, each for its own number of batches);
+// otherwise the emission inline in the batch (rays that stand inside the object and emit in every batch).  Same
+// operations per ray in the same order either way.
+template <int LOOK, bool SINGLE, bool PHASED, class Emit>
 CED_HD int traverse_ray_frame(const GridSpec &G, const AccelSpec &S, bool start_coarse, const float (&o)[3],
                               const float (&d)[3], float near, float far, const float *__restrict__ ts_row,
                               const int64_t *__restrict__ ti_row, const uint8_t *__restrict__ hit_row, Emit &&emit,
@@ -260,8 +273,22 @@ CED_HD int traverse_ray_frame(const GridSpec &G, const AccelSpec &S, bool start_
         const float this_tmax = fminf(seg_b, far);
         if (this_tmin >= this_tmax) continue;
         if (!continuous) push_skip(this_tmin);
-        // DDA set-up: the reference's arithmetic, operation for operation
         const float *ab = G.aabbs + 6 * lvl;
+        // A segment that starts with a sphere trace is traced BEFORE the DDA is set up: most segments of a frame's
+        // first iteration are empty, and those never need the set-up (twelve divisions).  The trace itself only needs
+        // the ray and the level's box; what it returns is used by the first round below, unchanged.
+        bool coarse = accel && start_coarse;
+        bool traced = false;
+        float t_stop0 = 0.0f, cells0 = 0.0f;
+        if (coarse) {
+            if (coarse_advance(S, lvl, res, ab, o, d, this_tmin, this_tmax, t_stop0, cells0)) {
+                continuous = false;            // the whole segment is empty cells
+                continue;
+            }
+            traced = true;
+        }
+        CED_DIAG_TICK(1);
+        // DDA set-up: the reference's arithmetic, operation for operation
         float tdist[3], delta[3];
         int cur[3], stp[3], ovf[3];
         const float ts = this_tmin + eps, te = this_tmax - eps;
@@ -282,7 +309,6 @@ CED_HD int traverse_ray_frame(const GridSpec &G, const AccelSpec &S, bool start_
             ovf[a] = fin + stp[a];
         }
         const uint8_t *grid = G.binaries + (int64_t)lvl * res * res * res;
-        bool coarse = accel && start_coarse;
         float t_c = this_tmin;                 // the time at which the walk stands (entry of the current cell)
         bool dda_done = false;
         int safe_cell = (cur[0] * res + cur[1]) * res + cur[2];
@@ -292,12 +318,15 @@ CED_HD int traverse_ray_frame(const GridSpec &G, const AccelSpec &S, bool start_
         while (!dda_done) {
             if (coarse) {
                 coarse = false;
-                float t_stop, cells;
-                if (coarse_advance(S, lvl, res, ab, o, d, t_c, this_tmax, t_stop, cells)) {
+                float t_stop = t_stop0, cells = cells0;
+                if (traced) {
+                    traced = false;            // the trace from the segment's start, done above
+                } else if (coarse_advance(S, lvl, res, ab, o, d, t_c, this_tmax, t_stop, cells)) {
                     continuous = false;        // the rest of the segment is empty cells
                     break;
                 }
                 if (cells >= kMinJumpCells) {          // shorter stretches are cheaper walked than jumped
+                    CED_DIAG_TICK(3);
                     // re-enter the exact DDA at t_stop: per axis, take every boundary crossing with T < t_stop
                     float last_event = t_c;
                     bool any = false;
@@ -325,76 +354,180 @@ CED_HD int traverse_ray_frame(const GridSpec &G, const AccelSpec &S, bool start_
                     if (dda_done) break;
                 }
             }
-            // exact walk, LOOK cells at a time: the path does not depend on the occupancy values, so the bytes of
-            // those cells -- and the empty radius of the cell the walk will stand in afterwards -- are fetched
-            // together (branch-free look-ahead, independent loads)
-            do {
+            if constexpr (PHASED) {
+                // exact walk, LOOK cells at a time: the path does not depend on the occupancy values, so the bytes of
+                // those cells -- and the empty radius of the cell the walk will stand in afterwards -- are fetched
+                // together (branch-free look-ahead, independent loads).  The walk loop only LOOKS: it runs until a batch
+                // holds an occupied cell (or the walk ends / wants to trace again) and leaves the batch for the emission
+                // phase below.  The lanes of a wave reach their first occupied cell in different batches; with the
+                // emission inline every such batch paid a pass through the emission code (the skip-march above all) for
+                // a handful of lanes -- three quarters of the instructions of a frame's first iteration.
                 float tt[LOOK];
-                int cellv[LOOK];
-                bool valid[LOOK];
-#pragma unroll
-                for (int b = 0; b < LOOK; ++b) {
-                    const bool live = !dda_done;
-                    valid[b] = live;
-                    tt[b] = fminf(fminf(tdist[0], fminf(tdist[1], tdist[2])), this_tmax);
-                    const int cell = (cur[0] * res + cur[1]) * res + cur[2];
-                    safe_cell = live ? cell : safe_cell;                // never form an out-of-grid address
-                    cellv[b] = safe_cell;
-                    const bool sx = (tdist[0] < tdist[1]) && (tdist[0] < tdist[2]);
-                    const bool sy = !sx && (tdist[1] < tdist[2]);
-                    const bool sz = !sx && !sy;
-                    const float nx = tdist[0] + delta[0], ny = tdist[1] + delta[1], nz = tdist[2] + delta[2];
-                    tdist[0] = (live && sx) ? nx : tdist[0];
-                    tdist[1] = (live && sy) ? ny : tdist[1];
-                    tdist[2] = (live && sz) ? nz : tdist[2];
-                    cur[0] += (live && sx) ? stp[0] : 0;
-                    cur[1] += (live && sy) ? stp[1] : 0;
-                    cur[2] += (live && sz) ? stp[2] : 0;
-                    const bool over = (sx && cur[0] == ovf[0]) || (sy && cur[1] == ovf[1]) || (sz && cur[2] == ovf[2]);
-                    dda_done = dda_done || (live && over);
-                }
-                uint8_t occ[LOOK];
-#pragma unroll
-                for (int b = 0; b < LOOK; ++b) occ[b] = grid[cellv[b]];
+                unsigned valid_mask = 0, occ_mask = 0;
                 int radius = 0;
-                if (accel) {
-                    const int c0 = dda_done ? 0 : cur[0], c1 = dda_done ? 0 : cur[1], c2 = dda_done ? 0 : cur[2];
-                    radius = empty_radius(S, lvl, res, c0, c1, c2);
-                }
                 bool last_empty = false;
-#pragma unroll
-                for (int b = 0; b < LOOK; ++b) {
-                    if (!valid[b]) continue;
-                    const float t_trav = tt[b];
-                    if (!occ[b]) {
-                        push_skip(t_trav);
-                        continuous = false;
-                        last_empty = true;
-                        t_c = t_trav;
-                        continue;
+                do {
+                    CED_DIAG_TICK(4);
+                    int cellv[LOOK];
+                    valid_mask = 0;
+    #pragma unroll
+                    for (int b = 0; b < LOOK; ++b) {
+                        const bool live = !dda_done;
+                        valid_mask |= live ? (1u << b) : 0u;
+                        tt[b] = fminf(fminf(tdist[0], fminf(tdist[1], tdist[2])), this_tmax);
+                        const int cell = (cur[0] * res + cur[1]) * res + cur[2];
+                        safe_cell = live ? cell : safe_cell;                // never form an out-of-grid address
+                        cellv[b] = safe_cell;
+                        const bool sx = (tdist[0] < tdist[1]) && (tdist[0] < tdist[2]);
+                        const bool sy = !sx && (tdist[1] < tdist[2]);
+                        const bool sz = !sx && !sy;
+                        const float nx = tdist[0] + delta[0], ny = tdist[1] + delta[1], nz = tdist[2] + delta[2];
+                        tdist[0] = (live && sx) ? nx : tdist[0];
+                        tdist[1] = (live && sy) ? ny : tdist[1];
+                        tdist[2] = (live && sz) ? nz : tdist[2];
+                        cur[0] += (live && sx) ? stp[0] : 0;
+                        cur[1] += (live && sy) ? stp[1] : 0;
+                        cur[2] += (live && sz) ? stp[2] : 0;
+                        const bool over = (sx && cur[0] == ovf[0]) || (sy && cur[1] == ovf[1]) || (sz && cur[2] == ovf[2]);
+                        dda_done = dda_done || (live && over);
                     }
+                    uint8_t occ[LOOK];
+    #pragma unroll
+                    for (int b = 0; b < LOOK; ++b) occ[b] = grid[cellv[b]];
+                    radius = 0;
+                    if (accel) {
+                        const int c0 = dda_done ? 0 : cur[0], c1 = dda_done ? 0 : cur[1], c2 = dda_done ? 0 : cur[2];
+                        radius = empty_radius(S, lvl, res, c0, c1, c2);
+                    }
+                    occ_mask = 0;
+    #pragma unroll
+                    for (int b = 0; b < LOOK; ++b) occ_mask |= occ[b] ? (1u << b) : 0u;
+                    occ_mask &= valid_mask;
+                    // the empty cells in front of the batch's first occupied one (all of its cells when it has none)
                     last_empty = false;
-                    if (has_skip) { t_last = skip_march_lattice(G, t_last, skip_to); has_skip = false; }
-                    for (;;) {
-                        float t_next;
-                        if (step_size <= 0.0f) {
-                            t_next = t_trav;
-                        } else {
-                            const float dt = calc_dt(t_last, cone_angle, step_size, 1e10f);
-                            if (t_last + dt * 0.5f >= t_trav) break;
-                            t_next = t_last + dt;
+    #pragma unroll
+                    for (int b = 0; b < LOOK; ++b) {
+                        const bool before = (valid_mask >> b & 1u) && (occ_mask & ((2u << b) - 1u)) == 0u;
+                        if (before) {
+                            push_skip(tt[b]);
+                            continuous = false;
+                            last_empty = true;
+                            t_c = tt[b];
                         }
-                        emit(n, t_last, t_next);
-                        n += 1;
-                        continuous = true;
-                        t_last = t_next;
-                        if (n >= limit) { t_term = t_last; return n; }      // budget used up: the ray stays alive
-                        if (t_next >= t_trav) break;
                     }
+                    if (occ_mask) break;
+                    // in empty space with room around the cell the walk stands in: trace ahead
+                    coarse = last_empty && radius >= kCoarseRadius;
+                } while (!dda_done && !coarse);
+                if (occ_mask) {
+                    // emission phase: the batch's cells from its first occupied one on, in order -- ONE copy of the code,
+                    // every lane with its own cursor
+                    CED_DIAG_TICK(5);
+                    for (int b = __builtin_ctz(occ_mask); b < LOOK; ++b) {
+                        if (!(valid_mask >> b & 1u)) break;                 // the walk ended inside the batch
+                        float t_trav = tt[0];
+    #pragma unroll
+                        for (int k = 1; k < LOOK; ++k) t_trav = b == k ? tt[k] : t_trav;
+                        if (!(occ_mask >> b & 1u)) {
+                            push_skip(t_trav);
+                            continuous = false;
+                            last_empty = true;
+                            t_c = t_trav;
+                            continue;
+                        }
+                        last_empty = false;
+                        if (has_skip) { t_last = skip_march_lattice(G, t_last, skip_to); has_skip = false; }
+                        for (;;) {
+                            float t_next;
+                            if (step_size <= 0.0f) {
+                                t_next = t_trav;
+                            } else {
+                                const float dt = calc_dt(t_last, cone_angle, step_size, 1e10f);
+                                if (t_last + dt * 0.5f >= t_trav) break;
+                                t_next = t_last + dt;
+                            }
+                            emit(n, t_last, t_next);
+                            n += 1;
+                            continuous = true;
+                            t_last = t_next;
+                            if (n >= limit) { t_term = t_last; return n; }      // budget used up: the ray stays alive
+                            if (t_next >= t_trav) break;
+                        }
+                    }
+                    coarse = last_empty && radius >= kCoarseRadius;
                 }
-                // in empty space with room around the cell the walk stands in: trace ahead
-                coarse = last_empty && radius >= kCoarseRadius;
-            } while (!dda_done && !coarse);
+            } else {
+                // exact walk, LOOK cells at a time: the path does not depend on the occupancy values, so the bytes of
+                // those cells -- and the empty radius of the cell the walk will stand in afterwards -- are fetched
+                // together (branch-free look-ahead, independent loads)
+                do {
+                    float tt[LOOK];
+                    int cellv[LOOK];
+                    bool valid[LOOK];
+    #pragma unroll
+                    for (int b = 0; b < LOOK; ++b) {
+                        const bool live = !dda_done;
+                        valid[b] = live;
+                        tt[b] = fminf(fminf(tdist[0], fminf(tdist[1], tdist[2])), this_tmax);
+                        const int cell = (cur[0] * res + cur[1]) * res + cur[2];
+                        safe_cell = live ? cell : safe_cell;                // never form an out-of-grid address
+                        cellv[b] = safe_cell;
+                        const bool sx = (tdist[0] < tdist[1]) && (tdist[0] < tdist[2]);
+                        const bool sy = !sx && (tdist[1] < tdist[2]);
+                        const bool sz = !sx && !sy;
+                        const float nx = tdist[0] + delta[0], ny = tdist[1] + delta[1], nz = tdist[2] + delta[2];
+                        tdist[0] = (live && sx) ? nx : tdist[0];
+                        tdist[1] = (live && sy) ? ny : tdist[1];
+                        tdist[2] = (live && sz) ? nz : tdist[2];
+                        cur[0] += (live && sx) ? stp[0] : 0;
+                        cur[1] += (live && sy) ? stp[1] : 0;
+                        cur[2] += (live && sz) ? stp[2] : 0;
+                        const bool over = (sx && cur[0] == ovf[0]) || (sy && cur[1] == ovf[1]) || (sz && cur[2] == ovf[2]);
+                        dda_done = dda_done || (live && over);
+                    }
+                    uint8_t occ[LOOK];
+    #pragma unroll
+                    for (int b = 0; b < LOOK; ++b) occ[b] = grid[cellv[b]];
+                    int radius = 0;
+                    if (accel) {
+                        const int c0 = dda_done ? 0 : cur[0], c1 = dda_done ? 0 : cur[1], c2 = dda_done ? 0 : cur[2];
+                        radius = empty_radius(S, lvl, res, c0, c1, c2);
+                    }
+                    bool last_empty = false;
+    #pragma unroll
+                    for (int b = 0; b < LOOK; ++b) {
+                        if (!valid[b]) continue;
+                        const float t_trav = tt[b];
+                        if (!occ[b]) {
+                            push_skip(t_trav);
+                            continuous = false;
+                            last_empty = true;
+                            t_c = t_trav;
+                            continue;
+                        }
+                        last_empty = false;
+                        if (has_skip) { t_last = skip_march_lattice(G, t_last, skip_to); has_skip = false; }
+                        for (;;) {
+                            float t_next;
+                            if (step_size <= 0.0f) {
+                                t_next = t_trav;
+                            } else {
+                                const float dt = calc_dt(t_last, cone_angle, step_size, 1e10f);
+                                if (t_last + dt * 0.5f >= t_trav) break;
+                                t_next = t_last + dt;
+                            }
+                            emit(n, t_last, t_next);
+                            n += 1;
+                            continuous = true;
+                            t_last = t_next;
+                            if (n >= limit) { t_term = t_last; return n; }      // budget used up: the ray stays alive
+                            if (t_next >= t_trav) break;
+                        }
+                    }
+                    // in empty space with room around the cell the walk stands in: trace ahead
+                    coarse = last_empty && radius >= kCoarseRadius;
+                } while (!dda_done && !coarse);
+            }
         }
     }
     t_term = t_last;            // n < limit: unspecified by contract (pending skips are not applied)

@@ -83,7 +83,9 @@ const char *ced_last_error_string(void);
  * any CU takes more (shorter last round, lower frame latency), 0 = contiguous tiles per workgroup;
  * "field_stagger": start-up phase offset between the waves of a SIMD (0 = none, default);
  * "march_early_out": 1 (default) lets the frame renderer's marching cross empty space through the brick distance
- * field, 0 walks every cell. */
+ * field, 0 walks every cell;
+ * "march_two_pass": the frame renderer's first iteration as a culling pass (the sphere trace alone, every ray) and a
+ * marching pass over the rays it could not rule out: 1 / 0, -1 (default) = when there are several grid levels. */
 int ced_set_option(const char *key, int value);
 
 /* Arithmetic of xyz_wrap / mlp_base / mlp_head (everything else is fp32 in every mode):
@@ -180,7 +182,10 @@ int ced_build_occupancy_accel(const uint8_t *binaries, int32_t n_grids, int32_t 
  * cell-by-cell walk, 1 = brick field only (what a render call builds for itself), 2 = brick + cell fields (what
  * ced_build_occupancy_accel provides).  use_lattice: far skips start from the table of first lattice points per
  * binade, as in a frame with cone_angle == 0 (every near plane must then be a point of the lattice t_0 = near_planes[0],
- * t_{k+1} = t_k + step: the frame's near plane or an earlier termination plane).  All pointers are host pointers. */
+ * t_{k+1} = t_k + step: the frame's near plane or an earlier termination plane).  start_coarse: 0 = the walk of a
+ * frame's later iterations (no trace at a segment's start, emission inline), 1 = a frame's first iteration (trace
+ * first, looking loop + emission phase), 2 = the one-shot march (trace first, emission inline).  All pointers are
+ * host pointers. */
 int ced_host_build_occupancy_accel(const uint8_t *binaries_host, int32_t n_grids, int32_t res, uint8_t *accel_host);
 int32_t ced_host_count_steps(float *x, float d, float tau, int32_t kcap, float *prev);
 int ced_host_march_frame(int64_t n_rays, const float *rays_o, const float *rays_d, const uint8_t *binaries,
