@@ -150,7 +150,7 @@ __global__ __launch_bounds__(256) void frame_times_kernel(int64_t n_rays, int ra
 __global__ __launch_bounds__(256) void frame_prep_kernel(int64_t n_rays, const float *__restrict__ rays_o,
                                                          const float *__restrict__ rays_d, int m,
                                                          const float *__restrict__ aabbs, float near_plane,
-                                                         float *__restrict__ t_sorted, int64_t *__restrict__ t_indices,
+                                                         float *__restrict__ t_sorted, uint8_t *__restrict__ t_indices,
                                                          uint8_t *__restrict__ hits, float *__restrict__ near_planes,
                                                          float *__restrict__ rgb,
                                                          float *__restrict__ opacity, float *__restrict__ depth)
@@ -179,7 +179,7 @@ __global__ __launch_bounds__(256) void frame_prep_kernel(int64_t n_rays, const f
     }
     for (int i = 0; i < 2 * m; ++i) {
         t_sorted[r * 2 * m + i] = ev[i];
-        t_indices[r * 2 * m + i] = id[i];
+        t_indices[r * 2 * m + i] = (uint8_t)id[i];
     }
     near_planes[r] = near_plane;
     rgb[3 * r] = 0.0f; rgb[3 * r + 1] = 0.0f; rgb[3 * r + 2] = 0.0f;
@@ -316,7 +316,7 @@ struct MarchArgs {
     const int32_t *alive;          // per-frame lists of the rays still alive (NULL: all rays, first iteration)
     int n_frames, rays_per_frame;
     const float *t_sorted;
-    const int64_t *t_indices;
+    const uint8_t *t_indices;      // event ids as bytes (nerfacc's int64 layout would be 64 B per ray at four levels)
     const uint8_t *hits;
     float *t_starts, *t_ends;      // ray-packed samples of the iteration
     int32_t *ray_idx;              // ray of every sample
@@ -374,14 +374,14 @@ __global__ __launch_bounds__(kCullThreads) void march_cull_kernel(MarchArgs A, I
             } else {
                 // the segments traverse_ray_frame visits, in its order (nerfacc's sorted entry / exit events)
                 const float *ts_row = A.t_sorted + r * 2 * m;
-                const int64_t *ti_row = A.t_indices + r * 2 * m;
+                const uint8_t *ti_row = A.t_indices + r * 2 * m;
                 const uint8_t *hit_row = A.hits + r * m;
                 for (int i = 0; i < 2 * m - 1 && !cand; ++i) {
-                    const int64_t ti = ti_row[i];
+                    const int ti = ti_row[i];
                     int lvl = (int)(ti % m);
                     if (!hit_row[lvl]) continue;
                     if (!(ti < m)) {
-                        const int64_t tn = ti_row[i + 1];
+                        const int tn = ti_row[i + 1];
                         if (tn < m) continue;
                         lvl = (int)(tn % m);
                         if (!hit_row[lvl]) continue;
@@ -462,7 +462,7 @@ __global__ __launch_bounds__(kMarchThreads, (SINGLE && !CAND) ? 4 : 3) void marc
             float prev_end = 0.0f;
             n = traverse_ray_frame<kFrameLook, SINGLE, FIRST>(
                 grid, A.accel, FIRST, o, d, near, A.far_plane,
-                SINGLE ? nullptr : A.t_sorted + r * 2 * m, SINGLE ? nullptr : A.t_indices + r * 2 * m,
+                SINGLE ? nullptr : A.t_sorted + r * 2 * m, SINGLE ? (const uint8_t *)nullptr : A.t_indices + r * 2 * m,
                 SINGLE ? nullptr : A.hits + r * m,
                 [&](int i, float t0, float t1) {
                     const bool fresh = i == 0 || t0 != prev_end;
@@ -506,7 +506,7 @@ __global__ __launch_bounds__(kMarchThreads, (SINGLE && !CAND) ? 4 : 3) void marc
                 float unused;                               // the walk again, storing at the final position
                 (void)traverse_ray_frame<kFrameLook, SINGLE, FIRST>(
                     grid, A.accel, FIRST, o, d, near, A.far_plane,
-                    SINGLE ? nullptr : A.t_sorted + r * 2 * m, SINGLE ? nullptr : A.t_indices + r * 2 * m,
+                    SINGLE ? nullptr : A.t_sorted + r * 2 * m, SINGLE ? (const uint8_t *)nullptr : A.t_indices + r * 2 * m,
                     SINGLE ? nullptr : A.hits + r * m,
                     [&](int i, float t0, float t1) { p0[i] = t0; p1[i] = t1; pr[i] = (int32_t)r; }, unused);
             } else {
@@ -1071,7 +1071,7 @@ __global__ __launch_bounds__(kMarchThreads, SINGLE ? 4 : 3) void march_all_onepa
 static inline size_t align_up(size_t x) { return (x + 255) & ~(size_t)255; }
 
 struct FrameWorkspace {
-    float *t_sorted; int64_t *t_indices; uint8_t *hits; float *near; int32_t *packed;
+    float *t_sorted; uint8_t *t_indices; uint8_t *hits; float *near; int32_t *packed;
     int32_t *alive_a, *alive_b;     // double-buffered list of alive ray ids
     IterPlan *plans;                // [max_iters + 1]
     float *lattice;                 // [256] first lattice point per binade (cone_angle == 0)
@@ -1105,7 +1105,7 @@ static FrameWorkspace carve(void *base, int64_t n, int m, int64_t cap, int max_i
     size_t off = 0;
     auto take = [&](size_t bytes) { size_t o = off; off = align_up(off + bytes); return (char *)base + o; };
     w.t_sorted = (float *)take((size_t)n * 2 * m * 4);
-    w.t_indices = (int64_t *)take((size_t)n * 2 * m * 8);
+    w.t_indices = (uint8_t *)take((size_t)n * 2 * m);
     w.hits = (uint8_t *)take((size_t)n * m);
     w.near = (float *)take((size_t)n * 4);
     w.packed = (int32_t *)take((size_t)n * 8);

@@ -224,10 +224,10 @@ CED_HD bool coarse_advance(const AccelSpec &S, int lvl, int res, const float *__
 // phase (a frame's first iteration: rays travel to their first occupied cell, each for its own number of batches);
 // otherwise the emission inline in the batch (rays that stand inside the object and emit in every batch).  Same
 // operations per ray in the same order either way.
-template <int LOOK, bool SINGLE, bool PHASED, class Emit>
+template <int LOOK, bool SINGLE, bool PHASED, class Idx, class Emit>
 CED_HD int traverse_ray_frame(const GridSpec &G, const AccelSpec &S, bool start_coarse, const float (&o)[3],
                               const float (&d)[3], float near, float far, const float *__restrict__ ts_row,
-                              const int64_t *__restrict__ ti_row, const uint8_t *__restrict__ hit_row, Emit &&emit,
+                              const Idx *__restrict__ ti_row, const uint8_t *__restrict__ hit_row, Emit &&emit,
                               float &t_term)
 {
     const float eps = 1e-6f;
@@ -256,12 +256,12 @@ CED_HD int traverse_ray_frame(const GridSpec &G, const AccelSpec &S, bool start_
         if constexpr (SINGLE) {
             if (!slab_test(o, inv_d, G.aabbs, seg_a, seg_b)) break;
         } else {
-            const int64_t ti = ti_row[i];
+            const int ti = (int)ti_row[i];          // event ids are < 2 * n_grids (int64 in nerfacc's layout, bytes in the frame renderer's)
             const bool entering = ti < n_grids;
             lvl = (int)(ti % n_grids);
             if (!hit_row[lvl]) continue;
             if (!entering) {
-                const int64_t tn = ti_row[i + 1];
+                const int tn = (int)ti_row[i + 1];
                 if (tn < n_grids) continue;
                 lvl = (int)(tn % n_grids);
                 if (!hit_row[lvl]) continue;

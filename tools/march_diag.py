@@ -29,11 +29,14 @@ read.restype = C.c_int; read.argtypes = [C.POINTER(C.c_ulonglong), C.c_int]
 NAMES = ["ray set-up", "segment set-up", "field probe", "re-entry", "walk batch", "emission", "reserve+regen", "tail"]
 waves = L.ced_diag_march_waves
 waves.restype = C.c_int; waves.argtypes = [C.POINTER(C.c_uint), C.c_int, C.c_int]
-def wave_report():
+def wave_report(skip=0):
     cap = 1 << 17
     buf = (C.c_uint * (cap * 24))()
     n = waves(buf, cap, 1)
-    w = np.frombuffer(buf, dtype=np.uint32)[: n * 24].reshape(n, 8, 3).astype(np.float64)
+    w = np.frombuffer(buf, dtype=np.uint32)[: n * 24].reshape(n, 8, 3).astype(np.float64)[skip:]
+    n -= skip
+    tot = w.sum(axis=0)
+    print("  phases of these waves: " + "  ".join(f"{NAMES[p]} {tot[p,0]:.0f} passes x {tot[p,1]/max(tot[p,0],1):.0f} lanes, {tot[p,2]/tot[:,2].sum()*100:.0f} % of cycles" for p in range(7) if tot[p,0]))
     cyc = w[:, :, 2].sum(axis=1)
     order = np.argsort(-cyc)
     print(f"  {n} wave records; cycles per wave: median {np.median(cyc):.0f}, p90 {np.percentile(cyc, 90):.0f}, p99 {np.percentile(cyc, 99):.0f}, max {cyc.max():.0f}")
@@ -44,7 +47,7 @@ def wave_report():
         r = w[i]
         print("   ", " ".join(f"{int(v):4d}" for v in r[:6, 0]), "|", " ".join(f"{(r[p,1] / max(r[p,0],1)):4.0f}" for p in range(6)),
               "|", " ".join(f"{r[p,2]/1e3:6.0f}" for p in range(7)), f"| total {cyc[i]/1e3:.0f}k")
-def report(title, max_samples):
+def report(title, max_samples, skip=0):
     render_image_test(max_samples, f, est, rays, timestamps=ts, **rk)
     torch.cuda.synchronize()
     buf = (C.c_ulonglong * 24)()
@@ -61,7 +64,8 @@ def report(title, max_samples):
               f"cycles {v[p,2]/cyc*100:5.1f} %  cycles/pass {v[p,2]/v[p,0]:8.0f}")
     util = (v[:, 2] * (v[:, 1] / np.maximum(v[:, 0], 1) / 64)).sum() / cyc
     print(f"  cycle-weighted lane utilisation {util*100:.0f} %")
-    wave_report()
+    wave_report(skip)
 ms = 1 if cfg["cone_angle"] == 0 else 4
 report("first iteration", ms)
+report("second iteration alone (rows after the first launch's)", ms + 1, skip=(W * H + 127) // 128 * 2 if cfg["grid_levels"] == 1 else 0)
 report("whole frame", 1024)

@@ -11,6 +11,6 @@ run() {  # scene two_pass libtag
   echo "== $sc two_pass=$tp lib=$tag"; grep "frame " $OUT/iter_${sc}_${tp}_$tag.log | tail -1; head -5 $OUT/timeline_${sc}_${tp}_$tag.txt | tail -3; grep -A8 "^frame:" $OUT/timeline_${sc}_${tp}_$tag.txt
   rm -rf $OUT/tr
 }
-for sc in ${SCENES:-dnerf dynerf hypernerf}; do
-  run $sc 0 base; run $sc 1 base; run $sc 1 cand64; run $sc 1 cand16
+for sc in ${SCENES:-dnerf dynerf}; do
+  for tag in ${TAGS:-base look8 look6 cr4 cr10 mj6}; do run $sc -1 $tag; done
 done
