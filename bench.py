@@ -513,6 +513,10 @@ def main():
     }
     if other_scaling is not None:
         line["other_scaling"] = other_scaling
+    if world > 1:
+        # the world size the collective backend itself reports (nccl = RCCL on ROCm), not the flag
+        line["rccl_ranks"] = int(dist.get_world_size())
+        line["rccl_backend"] = str(dist.get_backend())
     if comm_info is not None:
         line["comm"] = comm_info
     fk = prof.get("field", None)

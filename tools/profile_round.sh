@@ -3,12 +3,12 @@
 # profiles/).  Counters are collected in their own passes (never together with trace domains).
 # usage (on the GPU box): bash tools/profile_round.sh [tag]
 set -e
-TAG=${1:-r02_final}
+TAG=${1:-r03_final}
 R=$GRAFT_REPO_ROOT
 OUT=$R/gpurun_out/prof
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
-for prec in f32 f16x2; do
+for prec in ${MODES:-f32+h16x2 f32}; do
   ARGS="$R/bench.py --steps 5 --warmup 1 --no-cpu-baseline --also= --min-seconds 0 --mlp-precision $prec"
   # 1. the bench line itself (not under the profiler)
   timeout -k 10 300 python3 $ARGS > $OUT/${TAG}_${prec}_bench.json 2> $OUT/${TAG}_${prec}_bench.err
