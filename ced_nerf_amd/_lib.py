@@ -14,7 +14,7 @@ _PKG = os.path.dirname(os.path.abspath(__file__))
 _ROOT = os.path.dirname(_PKG)
 LIB_PATH = os.environ.get("CED_NERF_LIB", os.path.join(_PKG, "libcednerf_hip.so"))
 SOURCES = ["runtime.hip", "march.hip", "composite.hip", "field.hip", "field_half.hip", "field_mixed.hip", "frame.hip", "occgrid.hip",
-           "raygen.hip", "wgrad.hip", "pixels.hip", "accel.hip", "linear.hip", "mlp.hip"]
+           "raygen.hip", "wgrad.hip", "pixels.hip", "accel.hip", "linear.hip", "mlp.hip", "train_glue.hip"]
 MLP_F32, MLP_F16X2, MLP_F16, MLP_F32_HEAD16X2 = 0, 1, 2, 3          # ced_field_desc.mlp_precision
 # "f32+h16x2": sigma chain exact fp32 (counts / opacity / depth bit-identical to "f32"), colour head on split-fp16 MFMAs
 MLP_PRECISIONS = {"f32": MLP_F32, "f16x2": MLP_F16X2, "f16": MLP_F16, "f32+h16x2": MLP_F32_HEAD16X2}
@@ -135,6 +135,11 @@ PROTOTYPES = {
     "ced_render_image_workspace_bytes": (_i64, [_i64, _i64]),
     "ced_render_image": (C.c_int, [C.POINTER(FieldDesc), _i64, _vp, _vp, _i64, _vp, _vp, _vp, _f, _f, _vp, _i32, _vp, _vp, _vp,
                                    _vp, _vp, _vp, _i64, _vp, C.POINTER(_i64), _vp, _vp]),
+    "ced_train_inputs": (C.c_int, [_i64] + [_vp] * 13),
+    "ced_train_warp": (C.c_int, [_i64, _vp, _vp, _i32, _i32, _f, C.POINTER(C.c_float), _vp, _vp, _vp, _vp]),
+    "ced_train_warp_backward": (C.c_int, [_i64, _vp, _vp, _i32, _i32, _f, C.POINTER(C.c_float), _vp, _vp, _vp, _vp]),
+    "ced_train_head_in": (C.c_int, [_i64] + [_vp] * 6),
+    "ced_train_head_in_backward": (C.c_int, [_i64] + [_vp] * 6),
     "ced_render_image_gather": (C.c_int, [_i64, _i64, _i64, _vp, _i64, _vp, _i64, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
 }
 

@@ -396,6 +396,72 @@ def mlp_chain(x, weights, backward: bool = False, masks=None, want=None, relu_la
     return outs
 
 
+def train_inputs(n, rays_o=None, rays_d=None, ray_indices=None, t_starts=None, t_ends=None, timestamps=None,
+                 positions=None, directions=None):
+    """ced_train_inputs -> (pos [n,3], enc [n,32], sh [n,4], t [n]).  Rays mode (ray_indices given: int64 [n],
+    timestamps per RAY) or explicit mode (positions / directions [n,3], timestamps per sample)."""
+    ref = ray_indices if ray_indices is not None else positions
+    dev = ref.device
+    f32 = torch.float32
+    for t_, nm in ((rays_o, "rays_o"), (rays_d, "rays_d"), (t_starts, "t_starts"), (t_ends, "t_ends"),
+                   (timestamps, "timestamps"), (positions, "positions"), (directions, "directions")):
+        _chk(t_, f32, nm, allow_none=True)
+    _chk(ray_indices, torch.int64, "ray_indices", allow_none=True)
+    pos = torch.empty((n, 3), device=dev, dtype=f32)
+    enc = torch.empty((n, 32), device=dev, dtype=f32)
+    sh = torch.empty((n, 4), device=dev, dtype=f32)
+    t = torch.empty((n,), device=dev, dtype=f32)
+    rc = _lib.lib().ced_train_inputs(n, _p(rays_o), _p(rays_d), _p(ray_indices), _p(t_starts), _p(t_ends), _p(timestamps),
+                                     _p(positions), _p(directions), _p(pos), _p(enc), _p(sh), _p(t), _stream())
+    _lib.check(rc, "train_inputs")
+    return pos, enc, sh, t
+
+
+def train_warp(pos, mo, aabb6, moving_step: float, use_div_offsets: bool):
+    """ced_train_warp -> (xn clamped [n,3], move [n,3], selector [n] as 0 / 1 floats).  aabb6: six python floats."""
+    _chk(pos, torch.float32, "pos"); _chk(mo, torch.float32, "mo")
+    n = pos.shape[0]
+    xn, move = torch.empty_like(pos), torch.empty_like(pos)
+    sel = torch.empty((n,), device=pos.device, dtype=torch.float32)
+    rc = _lib.lib().ced_train_warp(n, _p(pos), _p(mo), mo.shape[1], int(bool(use_div_offsets)), float(moving_step),
+                                   (C.c_float * 6)(*aabb6), _p(xn), _p(move), _p(sel), _stream())
+    _lib.check(rc, "train_warp")
+    return xn, move, sel
+
+
+def train_warp_backward(pos, mo, aabb6, moving_step: float, use_div_offsets: bool, d_xn, d_move=None):
+    _chk(pos, torch.float32, "pos"); _chk(mo, torch.float32, "mo"); _chk(d_xn, torch.float32, "d_xn")
+    _chk(d_move, torch.float32, "d_move", allow_none=True)
+    d_mo = torch.empty_like(mo)
+    rc = _lib.lib().ced_train_warp_backward(pos.shape[0], _p(pos), _p(mo), mo.shape[1], int(bool(use_div_offsets)),
+                                            float(moving_step), (C.c_float * 6)(*aabb6), _p(d_xn), _p(d_move), _p(d_mo),
+                                            _stream())
+    _lib.check(rc, "train_warp_backward")
+    return d_mo
+
+
+def train_head_in(bout, sh, selector):
+    """ced_train_head_in -> (head_in [n,19], sigma [n])."""
+    _chk(bout, torch.float32, "bout"); _chk(sh, torch.float32, "sh"); _chk(selector, torch.float32, "selector")
+    assert bout.dim() == 2 and bout.shape[1] == 16 and sh.shape == (bout.shape[0], 4)
+    n = bout.shape[0]
+    head_in = torch.empty((n, 19), device=bout.device, dtype=torch.float32)
+    sigma = torch.empty((n,), device=bout.device, dtype=torch.float32)
+    rc = _lib.lib().ced_train_head_in(n, _p(bout), _p(sh), _p(selector), _p(head_in), _p(sigma), _stream())
+    _lib.check(rc, "train_head_in")
+    return head_in, sigma
+
+
+def train_head_in_backward(bout, selector, d_head_in, d_sigma):
+    _chk(bout, torch.float32, "bout"); _chk(selector, torch.float32, "selector")
+    _chk(d_head_in, torch.float32, "d_head_in", allow_none=True); _chk(d_sigma, torch.float32, "d_sigma", allow_none=True)
+    d_bout = torch.empty_like(bout)
+    rc = _lib.lib().ced_train_head_in_backward(bout.shape[0], _p(bout), _p(selector), _p(d_head_in), _p(d_sigma), _p(d_bout),
+                                               _stream())
+    _lib.check(rc, "train_head_in_backward")
+    return d_bout
+
+
 def weight_grad(x, dy):
     """ced_weight_grad: dW [n_out, n_in] = dy^T x over the sample stream (x [S, n_in], dy [S, n_out], fp32)."""
     _chk(x, torch.float32, "x"); _chk(dy, torch.float32, "dy")

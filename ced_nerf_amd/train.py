@@ -98,6 +98,50 @@ class _MlpFn(torch.autograd.Function):
         return (dz if ctx.needs_input_grad[0] else None, *grads)
 
 
+class _WarpFn(torch.autograd.Function):
+    """move / normalise / clamp / selector of cednerf/model.py:356-383 in one launch per direction (ced_train_warp)."""
+
+    @staticmethod
+    def forward(ctx, pos, mo, aabb6, moving_step, use_div):
+        mo_c = mo.detach().float().contiguous()
+        xn, move, sel = ops.train_warp(pos, mo_c, aabb6, moving_step, use_div)
+        ctx.save_for_backward(pos, mo_c)
+        ctx.cfg = (aabb6, moving_step, use_div)
+        ctx.mark_non_differentiable(sel)
+        ctx.set_materialize_grads(False)
+        return xn, move, sel
+
+    @staticmethod
+    def backward(ctx, d_xn, d_move, _d_sel):
+        pos, mo = ctx.saved_tensors
+        aabb6, moving_step, use_div = ctx.cfg
+        if d_xn is None:
+            d_xn = torch.zeros_like(pos)
+        d_mo = ops.train_warp_backward(pos, mo, aabb6, moving_step, use_div, d_xn.float().contiguous(),
+                                       None if d_move is None else d_move.float().contiguous())
+        return None, d_mo, None, None, None
+
+
+class _HeadInFn(torch.autograd.Function):
+    """density = trunc_exp(raw - 1) * selector and the colour head's input [SH, geo] (cednerf/model.py:414-417,455,
+    utils.py:27-43) in one launch per direction (ced_train_head_in)."""
+
+    @staticmethod
+    def forward(ctx, bout, sh, sel):
+        b = bout.detach().float().contiguous()
+        head_in, sigma = ops.train_head_in(b, sh, sel)
+        ctx.save_for_backward(b, sel)
+        ctx.set_materialize_grads(False)
+        return head_in, sigma
+
+    @staticmethod
+    def backward(ctx, d_head_in, d_sigma):
+        b, sel = ctx.saved_tensors
+        d_bout = ops.train_head_in_backward(b, sel, None if d_head_in is None else d_head_in.float().contiguous(),
+                                            None if d_sigma is None else d_sigma.float().contiguous())
+        return d_bout, None, None
+
+
 class _LinearFn(torch.autograd.Function):
     """One bias-free layer through the library (torch -> rocBLAS) for y and dx: kept ONLY as the A/B reference of the
     tests (`TrainableField.hip_mlp = False`); the training path itself uses `_MlpFn`."""
@@ -169,9 +213,66 @@ class TrainableField(torch.nn.Module):
             x = torch.relu(lin(x, w))
         return lin(x, weights[-1])
 
+    fused_glue = True               # False: the element-wise pieces as torch statements (the A/B reference of the tests)
+
     def forward(self, positions: torch.Tensor, t: torch.Tensor, directions: torch.Tensor, return_internal: bool = False):
         """positions [N,3] world, t [N,1] in [0,1], directions [N,3] -> (rgb [N,3], sigma [N]); with return_internal
         also the dict of cednerf/model.py:428-443 (`move`, `selector`, `latent_losses`, `weight_losses`)."""
+        if not self.fused_glue:
+            return self._forward_torch(positions, t, directions, return_internal)
+        n = positions.shape[0]
+        tt = t.reshape(-1).float()
+        if tt.shape[0] == 1 and n != 1:
+            tt = tt.expand(n)
+        pos, enc, sh, tt = ops.train_inputs(n, positions=positions.detach().float().contiguous(),
+                                            directions=directions.detach().float().contiguous(), timestamps=tt.contiguous())
+        return self._forward_core(pos, enc, sh, tt, return_internal)
+
+    def forward_rays(self, rays_o, rays_d, ray_indices, t_starts, t_ends, ts_per_ray, return_internal: bool = False):
+        """The same on ray-packed samples (what `rendering`'s rgb_sigma_fn hands over, cednerf/utils.py:86-104): positions
+        rays_o[r] + rays_d[r] * (t_start + t_end) / 2, directions rays_d[r], time ts_per_ray[r] -- gathered inside the
+        input kernel instead of by three torch index kernels."""
+        if not self.fused_glue:
+            pos = rays_o[ray_indices] + rays_d[ray_indices] * ((t_starts + t_ends)[:, None] / 2.0)
+            return self._forward_torch(pos, ts_per_ray.reshape(-1, 1)[ray_indices], rays_d[ray_indices], return_internal)
+        pos, enc, sh, tt = ops.train_inputs(ray_indices.shape[0], rays_o.contiguous(), rays_d.contiguous(),
+                                            ray_indices.contiguous(), t_starts.contiguous(), t_ends.contiguous(),
+                                            ts_per_ray.reshape(-1).float().contiguous())
+        return self._forward_core(pos, enc, sh, tt, return_internal)
+
+    def _forward_core(self, pos, enc, sh, tt, return_internal):
+        if getattr(self, "_aabb6", None) is None:
+            object.__setattr__(self, "_aabb6", [float(v) for v in self.aabb.detach().cpu().tolist()])
+        mo = self._mlp(enc, list(self.xyz_wrap))
+        xn, move, sel = _WarpFn.apply(pos, mo, self._aabb6, self.moving_step, self.use_div_offsets)   # model.py:356-383
+        hash_feat = feat = _HashFn.apply(xn, self.hash_table, self.hash_cfg)
+        if self.time_mode:                                                          # model.py:386-403 (no gradient there)
+            with torch.no_grad():
+                t1 = tt[:, None]
+                te = self.time_encoder(t1) if self.time_mode == 1 else \
+                    self.time_encoder_feat(t1, move.detach().norm(dim=-1, keepdim=True))
+            feat = torch.cat([feat, te], dim=-1)
+        bout = self._mlp(feat, list(self.mlp_base))
+        head_in, sigma = _HeadInFn.apply(bout, sh, sel)                             # model.py:105,414-417,455
+        rgb = torch.sigmoid(self._mlp(head_in, list(self.mlp_head)))
+        if not return_internal:
+            return rgb, sigma
+        selector = sel > 0.5
+        internal = {"move": move, "selector": selector}                              # model.py:428-443
+        if self.use_feat_predict or self.use_weight_predict:
+            x_move = (pos + move - self.aabb[:3]) / (self.aabb[3:] - self.aabb[:3])    # the unclamped normalised position
+            temp = _frequency4(torch.cat([x_move, tt[:, None]], dim=-1))
+            if self.use_feat_predict:
+                predict_feat = self._mlp(temp, list(self.mlp_feat_prediction))
+                internal["latent_losses"] = torch.nn.functional.huber_loss(predict_feat, hash_feat, reduction="none") \
+                    * selector[:, None].to(predict_feat.dtype)
+            if self.use_weight_predict:
+                internal["weight_losses"] = self._mlp(temp, list(self.mlp_weight_prediction))
+        return rgb, {"density": sigma[:, None], "interal_output": internal}
+
+    def _forward_torch(self, positions, t, directions, return_internal: bool = False):
+        """The element-wise pieces as torch statements (round 2's graph; kept as the reference the fused pieces are tested
+        against)."""
         x, tt = positions.float(), t.reshape(-1, 1).float()
         enc = _frequency4(torch.cat([x, tt], dim=-1))                               # [N,32]
         mo = self._mlp(enc, list(self.xyz_wrap))
@@ -181,9 +282,10 @@ class TrainableField(torch.nn.Module):
         xn = (x + move - self.aabb[:3]) / (self.aabb[3:] - self.aabb[:3])           # model.py:378-379
         selector = ((xn > 0.0) & (xn < 1.0)).all(dim=-1)                            # model.py:383
         hash_feat = feat = _HashFn.apply(xn.clamp(0.0, 1.0), self.hash_table, self.hash_cfg)
-        if self.time_mode:                                                          # model.py:386-403
-            mn = move.norm(dim=-1, keepdim=True)
-            te = self.time_encoder(tt) if self.time_mode == 1 else self.time_encoder_feat(tt, mn)
+        if self.time_mode:                                                          # model.py:386-403 (no gradient there)
+            with torch.no_grad():
+                mn = move.detach().norm(dim=-1, keepdim=True)
+                te = self.time_encoder(tt) if self.time_mode == 1 else self.time_encoder_feat(tt, mn)
             feat = torch.cat([feat, te], dim=-1)
         bout = self._mlp(feat, list(self.mlp_base))
         sigma = trunc_exp(bout[:, 0] - 1.0) * selector.to(bout.dtype)               # model.py:105,414-417
@@ -283,8 +385,7 @@ def train_step(field: TrainableField, estimator, optimizer, rays_o: torch.Tensor
     with_heads = field.use_feat_predict or field.use_weight_predict
 
     def rgb_sigma_fn(t_starts, t_ends, ray_indices):
-        pos = rays_o[ray_indices] + rays_d[ray_indices] * ((t_starts + t_ends)[:, None] / 2.0)
-        return field(pos, ts[ray_indices], rays_d[ray_indices], return_internal=with_heads)
+        return field.forward_rays(rays_o, rays_d, ray_indices, t_starts, t_ends, ts, return_internal=with_heads)
 
     colors, opacities, depths, extras = rendering_train(t_starts, t_ends, ray_indices, n_rays, rgb_sigma_fn,
                                                          render_bkgd=render_bkgd)

@@ -562,6 +562,34 @@ int ced_mlp_chain(int64_t n, int32_t n_layers, int32_t backward, const float *x,
                   const float *const *weights, float *const *outs, const float *const *masks, int32_t relu_last,
                   void *stream);
 
+/* Element-wise pieces of the DIFFERENTIABLE field between its MLPs and its hash grid (training path; the statements of
+ * cednerf/model.py:354-383,414-417,447-455 as train_real.py:339-420 differentiates them), one launch each.  fp32, device
+ * pointers, row-major.
+ * ced_train_inputs: per sample the position (rays mode, ray_indices != NULL: rays_o[r] + rays_d[r] * ((t_start + t_end) / 2),
+ *   time timestamps[r]; explicit mode: positions / directions / timestamps per sample), enc_out [n, 32] = tcnn
+ *   Frequency(4) of (x, y, z, t) ([dim][freq][sin, cos] of pi 2^k v), sh_out [n, 4] = SH degree 2 of the normalised
+ *   direction, t_out [n].  No backward: nothing upstream has parameters. */
+int ced_train_inputs(int64_t n, const float *rays_o, const float *rays_d, const int64_t *ray_indices,
+                     const float *t_starts, const float *t_ends, const float *timestamps, const float *positions,
+                     const float *directions, float *pos_out, float *enc_out, float *sh_out, float *t_out, void *stream);
+/* ced_train_warp: move = mo[:, :3] * moving_step (+ tanh(mo[:, 3:6]) * moving_step with use_div_offsets),
+ *   xn = clamp((pos + move - aabb_lo) / (aabb_hi - aabb_lo), 0, 1), selector = 1 where the unclamped xn lies strictly
+ *   inside (0, 1) on all axes, else 0.  aabb_host: six floats on the HOST.
+ * ced_train_warp_backward: d_mo [n, mo_width] from d_xn (passes where 0 <= unclamped xn <= 1, torch.clamp's rule) and
+ *   d_move (may be NULL). */
+int ced_train_warp(int64_t n, const float *pos, const float *mo, int32_t mo_width, int32_t use_div_offsets,
+                   float moving_step, const float *aabb_host, float *xn, float *move, float *selector, void *stream);
+int ced_train_warp_backward(int64_t n, const float *pos, const float *mo, int32_t mo_width, int32_t use_div_offsets,
+                            float moving_step, const float *aabb_host, const float *d_xn, const float *d_move,
+                            float *d_mo, void *stream);
+/* ced_train_head_in: sigma = exp(bout[:, 0] - 1) * selector (trunc_exp, cednerf/utils.py:27-43), head_in [n, 19] =
+ *   [sh (4), bout[:, 1:16]].  ced_train_head_in_backward: d_bout [n, 16] from d_head_in [n, 19] and d_sigma [n] (either may
+ *   be NULL = zero); the density's derivative is exp(min(raw - 1, 15)) as in the reference's _TruncExp.backward. */
+int ced_train_head_in(int64_t n, const float *bout, const float *sh, const float *selector, float *head_in,
+                      float *sigma, void *stream);
+int ced_train_head_in_backward(int64_t n, const float *bout, const float *selector, const float *d_head_in,
+                               const float *d_sigma, float *d_bout, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

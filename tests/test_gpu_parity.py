@@ -1902,6 +1902,60 @@ def test_trainable_field_gradients_hip_vs_library(oracle):
         assert (a - b).abs().max().item() <= 2e-4 * b.abs().max().item(), (name, (a - b).abs().max().item(), b.abs().max().item())
 
 
+@pytest.mark.parametrize("case", range(6))
+def test_trainable_field_fused_elementwise_pieces_match_the_torch_statements(oracle, case):
+    """The HIP pieces between the MLPs (ced_train_inputs / _warp / _head_in, one launch per direction) against the torch
+    statements they replaced (`fused_glue = False`): outputs, internal outputs and every parameter gradient, for all
+    flag combinations, through both entry points (explicit positions; ray-packed samples), points outside the box
+    included (selector 0, clamp's gradient rule)."""
+    from ced_nerf_amd import synthetic as S
+    from ced_nerf_amd.train import TrainableField
+    kw = dict(FIELD_CASES[case])
+    p = S.init_field_params([-1.5, -1.5, -1.5, 1.5, 1.5, 1.5], 1e-3, 1024, 17, regime="init", seed=21 + case, **kw)
+    p["hash"]["table"] = (p["hash"]["table"] * 3000.0).astype(np.float32)
+    tf = TrainableField(p, DEV, use_feat_predict=True, use_weight_predict=True)
+    rng = np.random.default_rng(60 + case)
+    n_rays, n = 512, 20000
+    ro = T(rng.uniform(-0.4, 0.4, size=(n_rays, 3)).astype(np.float32))
+    rd = rng.normal(size=(n_rays, 3)); rd = T((rd / np.linalg.norm(rd, axis=1, keepdims=True)).astype(np.float32))
+    ri = T(np.sort(rng.integers(0, n_rays, size=n)).astype(np.int64))
+    t0 = T(rng.uniform(0.0, 1.9, size=n).astype(np.float32)); t1 = t0 + 5e-3
+    ts = T(rng.uniform(0, 1, size=(n_rays, 1)).astype(np.float32))
+    wr = T(rng.normal(size=(n, 3)).astype(np.float32))
+    out = {}
+    for fused in (True, False):
+        tf.fused_glue = fused
+        for entry in ("rays", "explicit"):
+            tf.zero_grad(set_to_none=True)
+            if entry == "rays":
+                rgb, res = tf.forward_rays(ro, rd, ri, t0, t1, ts, return_internal=True)
+            else:
+                pos = ro[ri] + rd[ri] * ((t0 + t1)[:, None] / 2.0)
+                rgb, res = tf(pos, ts[ri], rd[ri], return_internal=True)
+            io = res["interal_output"]
+            loss = (rgb * wr).sum() + res["density"].sum() * 0.1 + io["latent_losses"].sum() * 1e3 + io["weight_losses"].sum() \
+                + (io["move"] * wr).sum() * 1e2
+            loss.backward()
+            out[(fused, entry)] = (rgb.detach(), res["density"].detach(), io["move"].detach(), io["selector"],
+                                   [q.grad.clone() for q in tf.parameters()])
+    tf.fused_glue = True
+    ref = out[(False, "explicit")]
+    assert 0 < int(ref[3].sum()) < n                  # some samples inside the box, some outside
+    for key in ((True, "rays"), (True, "explicit"), (False, "rays")):
+        got = out[key]
+        assert torch.equal(got[3], ref[3]), key
+        assert (got[0] - ref[0]).abs().max().item() <= 2e-6, key
+        assert ((got[1] - ref[1]).abs() <= 2e-5 * ref[1].abs() + 1e-12).all(), key
+        assert (got[2] - ref[2]).abs().max().item() <= 1e-9 + 2e-6 * ref[2].abs().max().item(), key
+        for (name, _), a, b in zip(tf.named_parameters(), got[4], ref[4]):
+            assert b.abs().max().item() > 0, name
+            # the Frequency terms differ in the last bit (torch.sin against the inference kernel's exact-reduction
+            # sin(pi y)), and the position gradient of the fine hash levels is piecewise constant: a sample that moves
+            # by 1e-8 across a cell face changes its contribution -- bounds in the norm, and a looser one on the maximum
+            assert (a - b).norm().item() <= 1e-3 * b.norm().item(), (key, name, (a - b).norm().item(), b.norm().item())
+            assert (a - b).abs().max().item() <= 5e-3 * b.abs().max().item(), (key, name, (a - b).abs().max().item(), b.abs().max().item())
+
+
 @pytest.mark.parametrize("name,alpha_thre", [("dnerf", 0.0), ("dnerf", 0.004), ("hypernerf", 0.0)])
 def test_sampling_on_the_native_visibility_pass(oracle, name, alpha_thre):
     """OccGridEstimator.sampling as the training step calls it (stratified near planes, per-ray timestamps): the
