@@ -101,7 +101,11 @@ struct HashBwdArgs {
 // wave first (segmented scan, stride 4).  The atomics are what bounds this kernel (requests, not bytes).
 __global__ __launch_bounds__(256) void hash_table_grad_kernel(HashBwdArgs A)
 {
-    const int64_t gid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  // grid-stride over the samples: the launch may be capped to a few workgroups per CU (ced_set_option
+  // "hash_grad_blocks"), so that a caller can run it beside compute-bound kernels of another stream -- the atomics
+  // are fire-and-forget and a handful of waves per CU keep the memory side's atomic units busy
+  for (int64_t gid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; gid - threadIdx.x < 4 * A.n;
+       gid += (int64_t)gridDim.x * blockDim.x) {
     const int64_t i = gid >> 2;
     const int feat = (int)(gid & 1), cx = (int)((gid >> 1) & 1);
     const int l = (int)blockIdx.y;
@@ -157,6 +161,7 @@ __global__ __launch_bounds__(256) void hash_table_grad_kernel(HashBwdArgs A)
         const bool last = lane >= 60 || next != idx;
         if (last && idx != 0xffffffffu && v != 0.0f) unsafeAtomicAdd(A.grad_table + (size_t)idx * 2 + feat, v);
     }
+  }
 }
 
 // LEVEL_MAJOR: blockIdx.y = level, consecutive lanes = consecutive samples -- a wave's atomics then fall into one
@@ -265,6 +270,7 @@ std::atomic<int> g_march_early_out{ 1 };        // frame renderer: conservative 
 std::atomic<int> g_march_two_pass{ -1 };        // frame renderer: first iteration as culling pass + marching of the rest (-1: when there are several grid levels)
 
 // launch-geometry variant of the field kernel (ced_set_option("field_variant", v))
+static std::atomic<int> g_hash_grad_blocks{ [] { const char *e = getenv("CED_HASH_GRAD_BLOCKS"); return e ? atoi(e) : 0; }() };
 static std::atomic<int> g_hash_grad_form{ []  { const char *e = getenv("CED_HASH_GRAD_FORM"); return e ? atoi(e) : 1; }() };   // 0: one corner per instruction
 static std::atomic<int> g_field_variant{ [] { const char *e = getenv("CED_FIELD_VARIANT"); return e ? atoi(e) : 2; }() };
 
@@ -397,6 +403,11 @@ extern "C" int ced_set_option(const char *key, int value)
     if (strcmp(key, "half_variant") == 0) {
         CED_REQUIRE(value >= 0 && value <= 2, "set_option: half_variant must be 0..2");
         ced::set_half_variant(value);
+        return CED_OK;
+    }
+    if (strcmp(key, "hash_grad_blocks") == 0) {
+        CED_REQUIRE(value >= 0 && value <= (1 << 20), "set_option: hash_grad_blocks must be 0 (no cap) .. 2^20");
+        ced::g_hash_grad_blocks = value;
         return CED_OK;
     }
     if (strcmp(key, "hash_grad_form") == 0) {
@@ -554,7 +565,7 @@ extern "C" int ced_hash_encode_backward(const ced_hash_desc *desc, int64_t n, co
     CED_REQUIRE(!desc->temporal, "hash_encode_backward: the temporal table has no backward yet");
     CED_REQUIRE(desc->n_levels <= 16, "hash_encode_backward: n_levels > 16");
     if (n == 0) return CED_OK;
-    CED_REQUIRE(x && dy && grad_table, "hash_encode_backward: null pointer");
+    CED_REQUIRE(x && dy && (grad_table || dx), "hash_encode_backward: null pointer");
     ced::HashBwdArgs A{};
     A.n = n; A.x = x; A.dy = dy; A.grad_table = grad_table; A.dx = dx;
     A.n_levels = desc->n_levels; A.table_dtype = desc->table_dtype; A.table = desc->table;
@@ -565,11 +576,16 @@ extern "C" int ced_hash_encode_backward(const ced_hash_desc *desc, int64_t n, co
     }
     const dim3 block(256);
     // table gradient: level-major; position gradient (optional): sample-major, no atomics
-    if (ced::g_hash_grad_form == 0) {
+    if (!grad_table) {
+        // position gradient only (the caller runs the table gradient elsewhere, e.g. on another stream)
+    } else if (ced::g_hash_grad_form == 0) {
         const dim3 grid_t((unsigned)((2 * n + 255) / 256), (unsigned)desc->n_levels);
         hipLaunchKernelGGL((ced::hash_backward_kernel<false, true>), grid_t, block, 0, (hipStream_t)stream, A);
     } else {
-        const dim3 grid_t((unsigned)((4 * n + 255) / 256), (unsigned)desc->n_levels);
+        int64_t gx = (4 * n + 255) / 256;
+        const int cap = ced::g_hash_grad_blocks;                // workgroups per level; <= 0: one per 64 samples
+        if (cap > 0 && gx > cap) gx = cap;
+        const dim3 grid_t((unsigned)gx, (unsigned)desc->n_levels);
         hipLaunchKernelGGL(ced::hash_table_grad_kernel, grid_t, block, 0, (hipStream_t)stream, A);
     }
     if (dx) {

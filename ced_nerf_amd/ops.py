@@ -166,12 +166,17 @@ def hash_encode(desc: _lib.HashDesc, x: torch.Tensor, t: Optional[torch.Tensor] 
 
 
 def hash_encode_backward(desc: _lib.HashDesc, x: torch.Tensor, dy: torch.Tensor,
-                         grad_table: Optional[torch.Tensor] = None, want_dx: bool = True, dx_scaled: bool = False):
-    """ced_hash_encode_backward: (grad_table [E,2] fp32 -- accumulated into when given, else fresh --, dx [n,3] or None)."""
+                         grad_table: Optional[torch.Tensor] = None, want_dx: bool = True, dx_scaled: bool = False,
+                         want_table: bool = True):
+    """ced_hash_encode_backward: (grad_table [E,2] fp32 -- accumulated into when given, else fresh --, dx [n,3] or None).
+    want_table=False: the position gradient alone (grad_table returned as None)."""
     _chk(x, torch.float32, "x"); _chk(dy, torch.float32, "dy")
     n = x.shape[0]
     assert x.shape == (n, 3) and dy.numel() == n * 2 * desc.n_levels, f"{x.shape} v.s. {dy.shape}"
-    if grad_table is None:
+    assert want_table or want_dx
+    if not want_table:
+        grad_table = None
+    elif grad_table is None:
         grad_table = torch.zeros((int(desc.total_entries), 2), device=x.device, dtype=torch.float32)
     else:
         _chk(grad_table, torch.float32, "grad_table")

@@ -23,7 +23,7 @@ from typing import Dict, Optional
 import numpy as np
 import torch
 
-from . import ops
+from . import _lib, ops
 from .hashgrid import level_tables
 from .render import rendering_train
 from .utils import trunc_exp
@@ -39,14 +39,64 @@ class _HashFn(torch.autograd.Function):
         ctx.cfg = cfg
         return out
 
+    # The table gradient is bound by the memory side's atomic request rate and nothing downstream of it in the
+    # backward pass needs it -- only the optimiser does.  With `side` set (train_step does, `_HashFn.deferred`), it is
+    # launched on a stream of its own, beside the position gradient and the motion MLP's backward that follow on the
+    # main stream (MFMA / HBM-bound), and handed to the parameter by `join_deferred()` before the optimiser step.
+    deferred = None            # None: everything on the current stream, the gradient returned through autograd
+    side_blocks_per_level = 32
+
     @staticmethod
     def backward(ctx, dy):
         x, tab = ctx.saved_tensors
         cfg = ctx.cfg
         desc, _ = ops.make_hash_desc(tab, cfg["base_res"], cfg["max_res"], cfg["n_levels"], cfg["log2_hashmap_size"], False)
-        grad_table, dx = ops.hash_encode_backward(desc, x, dy.float().contiguous(), want_dx=ctx.needs_input_grad[0],
-                                                  dx_scaled=True)
-        return dx, grad_table, None
+        dy = dy.float().contiguous()
+        d = _HashFn.deferred
+        if d is None or not ctx.needs_input_grad[1] or x.shape[0] == 0:
+            grad_table, dx = ops.hash_encode_backward(desc, x, dy, want_dx=ctx.needs_input_grad[0], dx_scaled=True)
+            return dx, grad_table, None
+        main = torch.cuda.current_stream()
+        grad_table = torch.zeros((int(desc.total_entries), 2), device=x.device, dtype=torch.float32)    # main stream's pool
+        d["side"].wait_stream(main)
+        with torch.cuda.stream(d["side"]):
+            # a few workgroups per CU (the atomics are fire-and-forget): room for the MLP kernels of the main stream.
+            # Uncapped, the launch's 400 k workgroups crowd them out and the overlap is worth 0.3 ms instead of 1.2
+            # (262 k rays: 12.4 -> 11.2 ms with 24-32 workgroups per level, 11.6 with 16, 11.9 with 48).
+            _lib.lib().ced_set_option(b"hash_grad_blocks", _HashFn.side_blocks_per_level)
+            try:
+                ops.hash_encode_backward(desc, x, dy, grad_table=grad_table, want_dx=False, dx_scaled=True)
+            finally:
+                _lib.lib().ced_set_option(b"hash_grad_blocks", 0)
+        for t_ in (x, dy, tab):
+            t_.record_stream(d["side"])                # their memory must not be handed out again before the kernel is over
+        d["pending"].append(grad_table)
+        dx = None
+        if ctx.needs_input_grad[0]:
+            _, dx = ops.hash_encode_backward(desc, x, dy, want_dx=True, dx_scaled=True, want_table=False)
+        return dx, None, None
+
+
+def begin_deferred_table_grad(device) -> None:
+    """From now on `_HashFn.backward` runs the table gradient on a side stream; `join_deferred_table_grad` ends it."""
+    d = getattr(_HashFn, "_side_cache", None)
+    if d is None or d["device"] != torch.device(device):
+        d = {"side": torch.cuda.Stream(device=device), "pending": [], "device": torch.device(device)}
+    d["pending"].clear()
+    _HashFn.deferred = d
+
+
+def join_deferred_table_grad(param: torch.nn.Parameter) -> None:
+    """Waits (stream-wise, not the host) for the side stream and adds the deferred gradients into param.grad."""
+    d = _HashFn.deferred
+    _HashFn.deferred = None
+    if d is None:
+        return
+    torch.cuda.current_stream().wait_stream(d["side"])
+    for g in d["pending"]:
+        param.grad = g if param.grad is None else param.grad + g
+    d["pending"].clear()
+    _HashFn._side_cache = d            # keep the stream for the next step
 
 
 class _MlpFn(torch.autograd.Function):
@@ -360,7 +410,8 @@ def refresh_occupancy(field: TrainableField, estimator, step: int, timestamps: t
 def train_step(field: TrainableField, estimator, optimizer, rays_o: torch.Tensor, rays_d: torch.Tensor,
                timestamps: torch.Tensor, target_rgb: torch.Tensor, render_step_size: float, near_plane: float = 0.0,
                far_plane: float = 1e10, cone_angle: float = 0.0, alpha_thre: float = 0.0,
-               render_bkgd: Optional[torch.Tensor] = None, grad_scaler=None, native_sampling: bool = True) -> Dict:
+               render_bkgd: Optional[torch.Tensor] = None, grad_scaler=None, native_sampling: bool = True,
+               overlap_table_grad: bool = True) -> Dict:
     """One optimisation step on a batch of rays (train_real.py:339-380): stratified occupancy-grid sampling with the
     current density (no gradient), differentiable field + compositing, smooth-L1 colour loss, optimiser step."""
     n_rays = rays_o.shape[0]
@@ -395,11 +446,19 @@ def train_step(field: TrainableField, estimator, optimizer, rays_o: torch.Tensor
     if "weight_losses" in extras:
         loss = loss + extras["weight_losses"].mean()
     optimizer.zero_grad(set_to_none=True)
-    if grad_scaler is not None:                            # train_real.py:252,414-419 (GradScaler(2**10))
-        grad_scaler.scale(loss).backward()
+    if overlap_table_grad:
+        begin_deferred_table_grad(rays_o.device)
+    try:
+        if grad_scaler is not None:                        # train_real.py:252,414-419 (GradScaler(2**10))
+            grad_scaler.scale(loss).backward()
+        else:
+            loss.backward()
+    finally:
+        if overlap_table_grad:
+            join_deferred_table_grad(field.hash_table)
+    if grad_scaler is not None:
         grad_scaler.step(optimizer)
         grad_scaler.update()
     else:
-        loss.backward()
         optimizer.step()
     return {"loss": float(loss.detach()), "n_samples": int(t_starts.shape[0])}

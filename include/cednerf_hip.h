@@ -211,7 +211,9 @@ int ced_hash_encode(const ced_hash_desc *desc, int64_t n, const float *x, const 
  * w.r.t. the encoder output; grad_table [total_entries, 2] fp32 is ACCUMULATED into (one hardware atomic add per
  * corner and feature; zero it first for a fresh gradient, as HashEncoder.backward does at :362-364); dx [n, 3]
  * (optional) receives the position gradient: dx_scaled = 0 as the reference computes it (per level w.r.t. the
- * scaled position, i.e. without the `scale` factor), dx_scaled = 1 the gradient w.r.t. x itself. */
+ * scaled position, i.e. without the `scale` factor), dx_scaled = 1 the gradient w.r.t. x itself.  grad_table may be
+ * NULL when dx is given (position gradient only): the two halves are independent launches and a caller may run them on
+ * different streams. */
 int ced_hash_encode_backward(const ced_hash_desc *desc, int64_t n, const float *x, const float *dy,
                              float *grad_table, float *dx, int32_t dx_scaled, void *stream);
 

@@ -24,7 +24,8 @@ for n_rays in [int(v) for v in os.environ.get("N_RAYS", "16384,65536,262144").sp
             torch.cuda.synchronize(); t0 = time.perf_counter()
         idx = torch.randint(0, o.shape[0], (n_rays,), device=dev, generator=g)
         out = train_step(field, est, opt, o[idx].contiguous(), d[idx].contiguous(), ts, target, cfg["render_step_size"],
-                         near_plane=cfg["near_plane"], far_plane=cfg["far_plane"], render_bkgd=bk)
+                         near_plane=cfg["near_plane"], far_plane=cfg["far_plane"], render_bkgd=bk,
+                         overlap_table_grad=os.environ.get("OVERLAP", "1") == "1")
         samples.append(out["n_samples"])
     torch.cuda.synchronize(); dt = (time.perf_counter() - t0) / 10
     print(f"train_step {n_rays} rays: {dt*1e3:.1f} ms/step, {np.mean(samples[3:]):.0f} samples kept/step, "
