@@ -10,12 +10,12 @@ import json, sys
 for l in sys.stdin:
     if l.startswith('{'):
         j = json.loads(l); o = j.get('other_mlp_precisions', {})
-        print('exact: %.0f Mrays/s %.3f Gsamples/s frac %.3f hbm %.3f' % (j['rays_per_sec'] / 1e6, j['value'] / 1e9, j['roofline']['frac'], j['roofline_hbm']['frac']))
+        print('%s: %.0f Mrays/s %.3f Gsamples/s frac %.3f hbm %.3f' % (j['mlp_precision'], j['rays_per_sec'] / 1e6, j['value'] / 1e9, j['roofline']['frac'], j['roofline_hbm']['frac']))
         for k, v in o.items():
             print('%s: %.0f Mrays/s %.3f Gsamples/s' % (k, v['rays_per_sec'] / 1e6, v['value'] / 1e9))
 "
 }
-# frames per call: 3 (bench.py's default) except for the small 400x400 frame, which gains from 8 per call
+# frames per call: 8 (bench.py default)
 run "C1 dnerf 400x400" --scene dnerf --width 400 --height 400 --frames-per-call 8
 run "C2 dnerf 800x800" --scene dnerf --width 800 --height 800
 run "C3 hypernerf 536x960" --scene hypernerf --width 536 --height 960
