@@ -135,6 +135,8 @@ PROTOTYPES = {
     "ced_render_image_workspace_bytes": (_i64, [_i64, _i64]),
     "ced_render_image": (C.c_int, [C.POINTER(FieldDesc), _i64, _vp, _vp, _i64, _vp, _vp, _vp, _f, _f, _vp, _i32, _vp, _vp, _vp,
                                    _vp, _vp, _vp, _i64, _vp, C.POINTER(_i64), _vp, _vp]),
+    "ced_mlp_backward_dw_workspace_bytes": (_i64, [_i64, _i32, C.POINTER(_i32)]),
+    "ced_mlp_backward_dw": (C.c_int, [_i64, _i32, _vp, C.POINTER(_i32), C.POINTER(_vp), C.POINTER(_vp), _vp, _vp, _vp, _i64, _vp]),
     "ced_train_inputs": (C.c_int, [_i64] + [_vp] * 13),
     "ced_train_warp": (C.c_int, [_i64, _vp, _vp, _i32, _i32, _f, C.POINTER(C.c_float), _vp, _vp, _vp, _vp]),
     "ced_train_warp_backward": (C.c_int, [_i64, _vp, _vp, _i32, _i32, _f, C.POINTER(C.c_float), _vp, _vp, _vp, _vp]),

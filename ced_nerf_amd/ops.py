@@ -401,6 +401,40 @@ def mlp_chain(x, weights, backward: bool = False, masks=None, want=None, relu_la
     return outs
 
 
+def mlp_backward_dw_supported(widths) -> bool:
+    """Shapes ced_mlp_backward_dw handles: input <= 48, 1..3 hidden layers of 64, output <= 32."""
+    L = len(widths) - 1
+    return 2 <= L <= 4 and 1 <= widths[0] <= 48 and 1 <= widths[L] <= 32 and all(w == 64 for w in widths[1:L])
+
+
+def mlp_backward_dw(dy, weights, acts, want_g0: bool):
+    """ced_mlp_backward_dw: dy [n, N_L], weights [W_0 .. W_H], acts [x, a_1 .. a_H] (the forward's layer inputs) ->
+    (g0 [n, K0] or None, [dW_0 .. dW_H])."""
+    _chk(dy, torch.float32, "dy")
+    L = len(weights)
+    widths = [weights[0].shape[1]] + [w.shape[0] for w in weights]
+    assert mlp_backward_dw_supported(widths) and len(acts) == L
+    n, dev = dy.shape[0], dy.device
+    for w, a, k in zip(weights, acts, widths):
+        _chk(w, torch.float32, "w"); _chk(a, torch.float32, "act")
+        assert a.shape == (n, k), f"{a.shape} v.s. {(n, k)}"
+    assert dy.shape == (n, widths[L])
+    total = sum(widths[l] * widths[l + 1] for l in range(L))
+    dws = torch.empty((total,), device=dev, dtype=torch.float32)
+    g0 = torch.empty((n, widths[0]), device=dev, dtype=torch.float32) if want_g0 else None
+    wa = (C.c_int32 * (L + 1))(*widths)
+    nbytes = int(_lib.lib().ced_mlp_backward_dw_workspace_bytes(n, L, wa))
+    ws = torch.empty((max(nbytes, 4) // 4,), device=dev, dtype=torch.float32)
+    vp = lambda ts: (C.c_void_p * L)(*[(t.data_ptr() if t.numel() > 0 else None) for t in ts])
+    rc = _lib.lib().ced_mlp_backward_dw(n, L, _p(dy), wa, vp(weights), vp(acts), _p(g0), _p(dws), _p(ws), nbytes, _stream())
+    _lib.check(rc, "mlp_backward_dw")
+    out, o = [], 0
+    for l in range(L):
+        out.append(dws[o:o + widths[l] * widths[l + 1]].view(widths[l + 1], widths[l]))
+        o += widths[l] * widths[l + 1]
+    return g0, out
+
+
 def train_inputs(n, rays_o=None, rays_d=None, ray_indices=None, t_starts=None, t_ends=None, timestamps=None,
                  positions=None, directions=None):
     """ced_train_inputs -> (pos [n,3], enc [n,32], sh [n,4], t [n]).  Rays mode (ray_indices given: int64 [n],

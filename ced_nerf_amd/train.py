@@ -106,6 +106,7 @@ class _MlpFn(torch.autograd.Function):
     cednerf/model.py:200-222,280-344)."""
 
     fused = True          # one launch per direction (ced_mlp_chain); False: layer by layer (ced_linear), same bits
+    fused_dw = True       # backward: the weight gradients inside the walk (ced_mlp_backward_dw); False: ced_weight_grad
 
     @staticmethod
     def forward(ctx, x, *weights):
@@ -129,6 +130,12 @@ class _MlpFn(torch.autograd.Function):
         acts, ws = ctx.saved_tensors[:n], ctx.saved_tensors[n:]
         dz = dy.float().contiguous()
         grads = [None] * n
+        widths = [ws[0].shape[1]] + [w.shape[0] for w in ws]
+        if (_MlpFn.fused and _MlpFn.fused_dw and dz.shape[0] > 0 and all(ctx.needs_input_grad[1:1 + n])
+                and ops.mlp_backward_dw_supported(widths)):
+            # the whole backward in one launch: every dW_l from the registers of the walk (ced_mlp_backward_dw)
+            g0, dws = ops.mlp_backward_dw(dz, list(ws), list(acts), want_g0=bool(ctx.needs_input_grad[0]))
+            return (g0, *dws)
         if _MlpFn.fused and dz.shape[0] > 0:
             # g_l = gradient at layer l's input: needed by dW_{l-1} (l >= 1) and, for l = 0, by the caller
             need_w = [bool(ctx.needs_input_grad[1 + l]) for l in range(n)]

@@ -564,6 +564,19 @@ int ced_mlp_chain(int64_t n, int32_t n_layers, int32_t backward, const float *x,
                   const float *const *weights, float *const *outs, const float *const *masks, int32_t relu_last,
                   void *stream);
 
+/* Backward of a whole MLP WITH its weight gradients, one launch (+ a fixed-order reduction): the walk of ced_mlp_chain's
+ * backward direction, with dW_l = dz_l^T a_l accumulated at every layer from the registers the walk holds (instead of
+ * ced_weight_grad re-reading every dz_l and a_l).  Shapes: input width <= 48, 1..3 hidden layers of width 64, output
+ * width <= 32 (n_layers = hidden layers + 1); CED_E_INVALID otherwise (callers fall back to ced_mlp_chain +
+ * ced_weight_grad).  widths as ced_mlp_chain; acts (host array of device pointers) [n_layers]: acts[0] = the network
+ * input x [n, widths[0]], acts[l] = the forward's (post-ReLU) output of layer l-1 [n, 64]; dy [n, widths[n_layers]].
+ * Outputs: dws (device, sum of widths[l] * widths[l+1] floats): dW_0, dW_1, ... back to back, each row-major
+ * [widths[l+1], widths[l]]; g0 [n, widths[0]] (gradient w.r.t. x) or NULL.  Deterministic (no float atomics). */
+int64_t ced_mlp_backward_dw_workspace_bytes(int64_t n, int32_t n_layers, const int32_t *widths);
+int ced_mlp_backward_dw(int64_t n, int32_t n_layers, const float *dy, const int32_t *widths,
+                        const float *const *weights, const float *const *acts, float *g0, float *dws, void *workspace,
+                        int64_t workspace_bytes, void *stream);
+
 /* Element-wise pieces of the DIFFERENTIABLE field between its MLPs and its hash grid (training path; the statements of
  * cednerf/model.py:354-383,414-417,447-455 as train_real.py:339-420 differentiates them), one launch each.  fp32, device
  * pointers, row-major.

@@ -1956,6 +1956,41 @@ def test_trainable_field_fused_elementwise_pieces_match_the_torch_statements(ora
             assert (a - b).abs().max().item() <= 5e-3 * b.abs().max().item(), (key, name, (a - b).abs().max().item(), b.abs().max().item())
 
 
+DW_NETS = [[32, 64, 64, 64, 3], [32, 64, 64, 64, 6], [32, 64, 16], [41, 64, 16], [19, 64, 64, 3], [32, 64, 32], [32, 64, 1],
+           [7, 64, 5], [48, 64, 64, 32]]
+
+
+@pytest.mark.parametrize("n", [1, 31, 33, 1000, 70001])
+def test_mlp_backward_with_weight_gradients_in_one_launch(oracle, n):
+    """ced_mlp_backward_dw against the two-step path it replaces: the input gradient equals ced_mlp_chain's bit for bit
+    (the same walk), every dW_l equals the oracle's float64 sum of dz_l^T a_l within the fp32 accumulation bound of
+    ced_weight_grad's test; every network shape of the model and ragged ones, sample counts that are not a multiple of
+    the 32-sample tile; two launches give the same bits (no float atomics)."""
+    from ced_nerf_amd import ops
+    rng = np.random.default_rng(300 + n)
+    for widths in DW_NETS:
+        L = len(widths) - 1
+        assert ops.mlp_backward_dw_supported(widths)
+        ws = [T((rng.normal(size=(widths[l + 1], widths[l])) / np.sqrt(widths[l])).astype(np.float32)) for l in range(L)]
+        x = T(rng.normal(size=(n, widths[0])).astype(np.float32))
+        acts = [x] + ops.mlp_chain(x, ws)[:-1]
+        dy = T((rng.normal(size=(n, widths[L])) * rng.uniform(0.1, 3.0, size=(1, widths[L]))).astype(np.float32))
+        g0, dws = ops.mlp_backward_dw(dy, ws, acts, want_g0=True)
+        g0_b, dws_b = ops.mlp_backward_dw(dy, ws, acts, want_g0=True)
+        g = ops.mlp_chain(dy, ws, backward=True, masks=[None] + acts[1:], want=[True] * L)
+        assert torch.equal(g0, g[0]) and torch.equal(g0, g0_b), widths
+        ups = g[1:] + [dy]
+        for l in range(L):
+            assert dws[l].shape == ws[l].shape and torch.equal(dws[l], dws_b[l])
+            a, dz = N(acts[l]), N(ups[l])
+            want = oracle.weight_grad(a, dz)
+            bound = 4e-6 * (np.abs(dz).astype(np.float64).T @ np.abs(a).astype(np.float64)) + 1e-30
+            assert (np.abs(N(dws[l]) - want) <= bound).all(), (widths, l, np.abs(N(dws[l]) - want).max())
+        _, dws_n = ops.mlp_backward_dw(dy, ws, acts, want_g0=False)
+        assert all(torch.equal(p_, q_) for p_, q_ in zip(dws, dws_n))
+    assert not ops.mlp_backward_dw_supported([32, 64, 48, 3]) and not ops.mlp_backward_dw_supported([64, 64, 3])
+
+
 def test_table_gradient_on_the_side_stream_is_the_same_gradient(oracle):
     """train_step's overlap_table_grad: the hash-table gradient launched on a stream of its own and handed to the
     parameter before the optimiser step equals the one autograd returns on the main stream (up to the order of the
@@ -2058,18 +2093,24 @@ def test_fused_mlp_chain_equals_layerwise(oracle, widths, n):
     some = ops.mlp_chain(dy, ws, backward=True, masks=masks, want=[l == 0 for l in range(L)])
     assert torch.equal(some[0], gs[0]) and all(t is None for t in some[1:])
     # autograd node: fused and layer-wise give the same output and the same parameter / input gradients
+    # (fused_dw: the weight gradients inside the backward walk -- another summation order, compared below)
     outs = {}
-    for fused in (True, False):
-        _MlpFn.fused = fused
+    for fused, fused_dw in ((True, False), (False, False), (True, True)):
+        _MlpFn.fused, _MlpFn.fused_dw = fused, fused_dw
         xi = x.clone().requires_grad_(True)
         wi = [w.clone().requires_grad_(True) for w in ws]
         y = _MlpFn.apply(xi, *wi)
         (y * dy).sum().backward()
-        outs[fused] = (y.detach(), xi.grad, [w.grad for w in wi])
-    _MlpFn.fused = True
-    assert torch.equal(outs[True][0], outs[False][0]) and torch.equal(outs[True][1], outs[False][1])
-    for a, b in zip(outs[True][2], outs[False][2]):
+        outs[(fused, fused_dw)] = (y.detach(), xi.grad, [w.grad for w in wi])
+    _MlpFn.fused, _MlpFn.fused_dw = True, True
+    ref = outs[(False, False)]
+    assert torch.equal(outs[(True, False)][0], ref[0]) and torch.equal(outs[(True, False)][1], ref[1])
+    for a, b in zip(outs[(True, False)][2], ref[2]):
         assert torch.equal(a, b)
+    one = outs[(True, True)]
+    assert torch.equal(one[0], ref[0]) and torch.equal(one[1], ref[1])          # the same walk: the same input gradient
+    for a, b in zip(one[2], ref[2]):
+        assert (a - b).abs().max().item() <= 2e-5 * b.abs().max().item() + 1e-30
 
 
 def test_training_steps_reduce_the_loss(oracle):

@@ -1,7 +1,7 @@
 # training path: the fused element-wise pieces -- parity tests, step time, kernel statistics of the 262k-ray step
 mkdir -p gpurun_out/r3t && cd $GRAFT_REPO_ROOT
 OUT=$GRAFT_REPO_ROOT/gpurun_out/r3t
-timeout -k 10 600 python -m pytest tests -m gpu -x -q --capture=sys -k "table_gradient or trainable or train_step or student or loss or rendering_train or mlp_chain or weight_grad" > $OUT/tests.log 2>&1; echo "tests rc=$?" | tee -a $OUT/tests.log
+timeout -k 10 600 python -m pytest tests -m gpu -x -q --capture=sys -k "mlp_backward or table_gradient or trainable or train_step or student or loss or rendering_train or mlp_chain or weight_grad" > $OUT/tests.log 2>&1; echo "tests rc=$?" | tee -a $OUT/tests.log
 tail -4 $OUT/tests.log
 for ov in 1; do echo "overlap_table_grad=$ov"; OVERLAP=$ov timeout -k 10 300 python tools/bench_train.py 2>&1 | grep train_step; done | tee $OUT/bench_train.txt
 cd /tmp && export TMPDIR=/tmp
