@@ -58,9 +58,12 @@ def parse():
                     help="per-launch HBM traffic of the field kernel from the rocprofv3 --pmc passes (tools/pmc_summary.py)")
     ap.add_argument("--regime", default="trained")
     ap.add_argument("--max-samples", type=int, default=1024)
-    ap.add_argument("--frames-per-call", type=int, default=int(os.environ.get("CED_FRAMES_PER_CALL", "8")),
+    ap.add_argument("--frames-per-call", type=int, default=int(os.environ.get("CED_FRAMES_PER_CALL", "0")),
                     help="frames rendered by one native call (ced_render_frames_test): they share the launches of an "
-                         "iteration, each on its own schedule; 1 = ced_render_image_test per frame")
+                         "iteration, each on its own schedule; 1 = ced_render_image_test per frame; 0 (default) = about "
+                         "10 M rays per call, 8..32 frames (800x800: 16; 400x400: 32; 1352x1014: 8): the smaller the "
+                         "frame, the more of them it takes to fill a launch (400x400: 8 -> 32 frames per call +12 %, "
+                         "800x800: 8 -> 16 +1.8 %, profiles/r03_sweep_frames_per_call.txt)")
     ap.add_argument("--frames-in-flight", type=int, default=3,
                     help="independent frames rendered concurrently per GPU (own stream + host thread each)")
     ap.add_argument("--scaling", default=None, choices=["weak", "strong"],
@@ -187,6 +190,8 @@ def main():
     lanes = max(1, args.frames_in_flight)
     if args.scaling is None:
         args.scaling = "strong" if world > 1 else "weak"
+    if args.frames_per_call <= 0:
+        args.frames_per_call = max(8, min(32, int(round(10.24e6 / float(args.width * args.height)))))
     per_call = max(1, min(64 // world, args.frames_per_call))
     # A unit of a native call is this rank's share of ONE frame in both modes (the frame's loop is the whole image's,
     # cednerf/utils.py:231-235).  strong: a call holds per_call frames (total work fixed: each rank renders 1/world of

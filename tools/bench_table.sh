@@ -16,7 +16,7 @@ for l in sys.stdin:
 "
 }
 # frames per call: 8 (bench.py default)
-run "C1 dnerf 400x400" --scene dnerf --width 400 --height 400 --frames-per-call 8
+run "C1 dnerf 400x400" --scene dnerf --width 400 --height 400
 run "C2 dnerf 800x800" --scene dnerf --width 800 --height 800
 run "C3 hypernerf 536x960" --scene hypernerf --width 536 --height 960
 run "C4 dynerf 1352x1014" --scene dynerf --width 1352 --height 1014
