@@ -461,6 +461,7 @@ CED_HD int traverse_ray_frame(const GridSpec &G, const AccelSpec &S, bool start_
                 // those cells -- and the empty radius of the cell the walk will stand in afterwards -- are fetched
                 // together (branch-free look-ahead, independent loads)
                 do {
+                    CED_DIAG_TICK(4);
                     float tt[LOOK];
                     int cellv[LOOK];
                     bool valid[LOOK];
@@ -506,6 +507,7 @@ CED_HD int traverse_ray_frame(const GridSpec &G, const AccelSpec &S, bool start_
                             continue;
                         }
                         last_empty = false;
+                        CED_DIAG_TICK(5);
                         if (has_skip) { t_last = skip_march_lattice(G, t_last, skip_to); has_skip = false; }
                         for (;;) {
                             float t_next;
