@@ -1198,6 +1198,51 @@ def test_render_frames_test_equals_frames_alone(oracle, name, max_samples):
         render_frames_test(64, f, est, many, timestamps=torch.zeros(65, device=DEV), **rk)
 
 
+@pytest.mark.parametrize("name", ["dnerf", "hypernerf", "dynerf"])
+def test_first_iteration_forms_give_the_same_frames(oracle, name):
+    """The first marching iteration has three forms -- one pass; culling pass + candidate list; the candidate list on
+    persistent waves with lane-level ray fetch (march_sm.hpp, off by default: measured slower) -- selected by
+    ced_set_option.  Every form renders the same frames bit for bit (several frames per call, a frame that sees nothing,
+    a sample budget that ends the loop early)."""
+    from ced_nerf_amd import _lib, synthetic as S
+    from ced_nerf_amd.model import DNGPradianceField
+    from ced_nerf_amd.nerfacc_api import OccGridEstimator
+    from ced_nerf_amd.utils import Rays, render_frames_test
+    W, H = 160, 120
+    sc = _scene(name, W, H, "trained", log2_hashmap_size=15)
+    cfg = sc["cfg"]
+    f = DNGPradianceField.from_params(sc["params"], DEV).eval()
+    est = OccGridEstimator(cfg["aabb"], cfg["grid_resolution"], cfg["grid_levels"]).to(DEV)
+    est.set_binaries(T(sc["binaries"]))
+    rk = dict(sc["render"]); rk["render_bkgd"] = T(rk["render_bkgd"])
+    os_, ds_ = [], []
+    for k, (elev, az, radius) in enumerate([(30.0, 10.0, 1.0), (55.0, 140.0, 0.8), (30.0, 40.0, 1.0), (5.0, 250.0, 1.6)]):
+        c2w = S.look_at_c2w(cfg["radius"] * radius, elev, az, cfg["opengl"])
+        if k == 2:
+            c2w = c2w.copy(); c2w[:3, :3] = -c2w[:3, :3]
+        o, d = S.make_camera_rays(W, H, cfg["camera_angle_x"], c2w, cfg["opengl"])
+        os_.append(T(o)); ds_.append(T(d))
+    rays = Rays(torch.stack(os_), torch.stack(ds_))
+    ts = torch.tensor([0.0, 0.3, 0.6, 1.0], device=DEV)
+    L = _lib.lib()
+    outs = {}
+    try:
+        for form, (two, sm) in {"one pass": (0, 0), "cull + list": (1, 0), "cull + lane fetch": (1, 1)}.items():
+            assert L.ced_set_option(b"march_two_pass", two) == 0 and L.ced_set_option(b"march_sm", sm) == 0
+            for ms in (1024, 24):
+                outs[(form, ms)] = render_frames_test(ms, f, est, rays, timestamps=ts, **rk)
+                torch.cuda.synchronize()
+    finally:
+        L.ced_set_option(b"march_two_pass", -1); L.ced_set_option(b"march_sm", 0)
+    for ms in (1024, 24):
+        ref = outs[("one pass", ms)]
+        assert sum(ref[3]) > 20000 and ref[3][2] == 0
+        for form in ("cull + list", "cull + lane fetch"):
+            got = outs[(form, ms)]
+            assert list(got[3]) == list(ref[3]), (form, ms, got[3], ref[3])
+            assert torch.equal(got[0], ref[0]) and torch.equal(got[1], ref[1]) and torch.equal(got[2], ref[2]), (form, ms)
+
+
 def test_sharded_renderer_units_equal_frames_alone(oracle):
     """ShardedRenderer(units=3) (bench.py's default at one GPU: three frames per native call, rays in 8x8-tile order,
     pixels un-permuted): every frame equals render_image_test on it alone; also through frames in flight."""

@@ -149,7 +149,7 @@ def test_march_frame_matches_oracle_on_the_dataset_shaped_scenes(hip, oracle, na
             near = np.full((n,), sc["render"]["near_plane"], np.float32)
             if resume:       # later iterations: every ray resumes at its own termination plane
                 near = (near + rng.uniform(0, 6, size=n)).astype(np.float32)
-            for start_coarse in (1, 0, 2):     # first iteration / later iterations / one-shot march
+            for start_coarse in (1, 0, 2, 3):  # first iteration / later iterations / one-shot march / state machine
                 for mode in (2, 1):          # brick + cell fields (a caller's accel); brick field only (built per call)
                     s, full, dist = _march_case(hip, oracle, sc, limit, near, start_coarse, accel_mode=mode)
                     total += s
@@ -202,7 +202,7 @@ def test_march_frame_matches_oracle_on_random_configurations(hip, oracle, seed):
         near = np.full((n,), sc["render"]["near_plane"], np.float32)
         if rng.random() < 0.5:
             near = (near + rng.uniform(0, 3, size=n)).astype(np.float32)
-        _march_case(hip, oracle, sc, limit, near, int(rng.integers(3)), accel_mode=int(rng.integers(1, 3)))
+        _march_case(hip, oracle, sc, limit, near, int(rng.integers(4)), accel_mode=int(rng.integers(1, 3)))
 
 
 def test_distance_fields_are_chebyshev_distances(hip):
