@@ -80,6 +80,7 @@ PROTOTYPES = {
     "ced_pack_field_weights_half": (C.c_int, [C.c_int, C.c_int, C.c_int] + [_vp] * 10),
     "ced_pack_field_weights_mixed": (C.c_int, [C.c_int, C.c_int] + [_vp] * 10),
     "ced_ray_aabb_intersect": (C.c_int, [_i64, _vp, _vp, _i32, _vp, _f, _f, _f, _vp, _vp, _vp, _vp]),
+    "ced_sort_intersections": (C.c_int, [_i64, _i32, _vp, _vp, _vp, _vp, _vp]),
     "ced_traverse_grids": (C.c_int, [_i64, _vp, _vp, _vp, _i32, _i32, _vp, _vp, _vp, _f, _f, _i32, _vp, _vp, _vp, _vp,
                                      _i32, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "ced_host_skip_march": (_f, [_f, _f, _f, _f]),

@@ -45,6 +45,8 @@ def ray_aabb_intersect(rays_o, rays_d, aabbs, near_plane: float = -float("inf"),
 def sort_intersections(t_mins, t_maxs):
     """The event list of cednerf/utils.py:219-225."""
     n_rays, n_grids = t_mins.shape
+    if n_grids > 1 and t_mins.is_cuda and n_grids <= 8:
+        return ops.sort_intersections(t_mins.contiguous(), t_maxs.contiguous())         # one HIP launch (torch.sort: 3 ms at C4)
     if n_grids > 1:
         t_sorted, t_indices = torch.sort(torch.cat([t_mins, t_maxs], -1), dim=-1, stable=True)
     else:

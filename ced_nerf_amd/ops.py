@@ -135,6 +135,19 @@ def ray_aabb_intersect(rays_o, rays_d, aabbs, near_plane=-float("inf"), far_plan
     return t_mins, t_maxs, hits
 
 
+def sort_intersections(t_mins, t_maxs):
+    """ced_sort_intersections: (t_sorted [n, 2m] f32, t_indices [n, 2m] int64) = torch.sort(cat([t_mins, t_maxs], -1),
+    stable=True) per ray, in one launch."""
+    _chk(t_mins, torch.float32, "t_mins"); _chk(t_maxs, torch.float32, "t_maxs")
+    assert t_mins.ndim == 2 and t_mins.shape == t_maxs.shape
+    n, m = t_mins.shape
+    t_sorted = torch.empty((n, 2 * m), device=t_mins.device, dtype=torch.float32)
+    t_indices = torch.empty((n, 2 * m), device=t_mins.device, dtype=torch.int64)
+    rc = _lib.lib().ced_sort_intersections(n, m, _p(t_mins), _p(t_maxs), _p(t_sorted), _p(t_indices), _stream())
+    _lib.check(rc, "sort_intersections")
+    return t_sorted, t_indices
+
+
 def traverse_grids_raw(rays_o, rays_d, binaries, aabbs, near_planes, far_planes, step_size, cone_angle, limit,
                        rays_mask, t_sorted, t_indices, hits, mode, base=None, counts=None, t_starts=None,
                        t_ends=None, ray_indices=None, termination_planes=None, packed_info_out=None):

@@ -144,6 +144,13 @@ int ced_ray_aabb_intersect(int64_t n_rays, const float *rays_o, const float *ray
                            float near_plane, float far_plane, float miss_value,
                            float *t_mins, float *t_maxs, uint8_t *hits, void *stream);
 
+/* The sorted entry / exit events of cednerf/utils.py:219-225: per ray, torch.sort(cat([t_mins, t_maxs], -1), stable=True).
+ * t_mins / t_maxs [n_rays, n_grids] (ced_ray_aabb_intersect's) -> t_sorted [n_rays, 2 n_grids], t_indices [n_rays,
+ * 2 n_grids] int64 (event id: level for an entry, n_grids + level for an exit), n_grids <= 8.  Equal keys keep their
+ * order, NaN keys sort last (torch's rules). */
+int ced_sort_intersections(int64_t n_rays, int32_t n_grids, const float *t_mins, const float *t_maxs, float *t_sorted,
+                           int64_t *t_indices, void *stream);
+
 /* nerfacc.traverse_grids(...) -- call sites cednerf/utils.py:241-264 and, via
  * OccGridEstimator.sampling, cednerf/utils.py:115-125.  The caller allocates, so the op is split:
  *   mode 0  count: writes counts[n_rays] and termination_planes (t_starts/t_ends/ray_indices unused);

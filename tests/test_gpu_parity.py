@@ -1198,6 +1198,35 @@ def test_render_frames_test_equals_frames_alone(oracle, name, max_samples):
         render_frames_test(64, f, est, many, timestamps=torch.zeros(65, device=DEV), **rk)
 
 
+@pytest.mark.parametrize("m", [1, 2, 3, 4, 8])
+def test_sort_intersections_is_torch_stable_sort(oracle, m):
+    """ced_sort_intersections (the event list of cednerf/utils.py:219-225 in one launch) against
+    torch.sort(cat([t_mins, t_maxs], -1), stable=True): values and indices, with ties (rays that miss a level carry +inf
+    twice; equal entry times of nested boxes), NaN keys and real ray/box intervals."""
+    from ced_nerf_amd import ops
+    from ced_nerf_amd.nerfacc_api import ray_aabb_intersect, sort_intersections
+    rng = np.random.default_rng(40 + m)
+    n = 50001
+    tmin = rng.uniform(0, 5, size=(n, m)).astype(np.float32)
+    tmax = (tmin + rng.uniform(0, 3, size=(n, m))).astype(np.float32)
+    tmin[::7] = np.inf; tmax[::7] = np.inf                       # misses
+    tmin[1::11, :] = tmin[1::11, :1]                              # ties between levels
+    tmax[2::13, 0] = tmin[2::13, m - 1]                           # an exit equal to an entry
+    tmin[5::1001, 0] = np.nan
+    a, b = T(tmin), T(tmax)
+    ts, ti = ops.sort_intersections(a, b)
+    want_s, want_i = torch.sort(torch.cat([a, b], -1), dim=-1, stable=True)
+    assert ti.dtype == torch.int64 and torch.equal(ti, want_i)
+    assert torch.equal(torch.nan_to_num(ts, nan=-1.0), torch.nan_to_num(want_s, nan=-1.0))
+    # through the nerfacc-shaped helper on real intersections
+    o = T(rng.uniform(-3, 3, size=(n, 3)).astype(np.float32)); d = rng.normal(size=(n, 3)); d /= np.linalg.norm(d, axis=1, keepdims=True)
+    aabbs = T(np.stack([[-(2.0 ** k)] * 3 + [2.0 ** k] * 3 for k in range(m)]).astype(np.float32))
+    t0, t1, _ = ray_aabb_intersect(o, T(d.astype(np.float32)), aabbs)
+    ts2, ti2 = sort_intersections(t0, t1)
+    w_s, w_i = torch.sort(torch.cat([t0, t1], -1), dim=-1, stable=True)
+    assert torch.equal(ti2, w_i if m > 1 else ti2) and torch.equal(ts2, w_s)
+
+
 @pytest.mark.parametrize("name", ["dnerf", "hypernerf", "dynerf"])
 def test_first_iteration_forms_give_the_same_frames(oracle, name):
     """The first marching iteration has three forms -- one pass; culling pass + candidate list; the candidate list on
