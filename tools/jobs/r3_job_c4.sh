@@ -2,7 +2,7 @@ mkdir -p gpurun_out/r3h && cd $GRAFT_REPO_ROOT
 OUT=gpurun_out/r3h
 timeout -k 10 900 python -m pytest tests -m gpu -x -q --capture=sys > $OUT/tests.log 2>&1; echo "tests rc=$?" | tee -a $OUT/tests.log
 tail -3 $OUT/tests.log
-SCENES="dynerf hypernerf" TAGS=base bash tools/r3_job_march_quick.sh 2>&1 | grep -E "^==|march_|frame_prep|frame:"
+SCENES="dynerf hypernerf" TAGS=base bash tools/jobs/r3_job_march_quick.sh 2>&1 | grep -E "^==|march_|frame_prep|frame:"
 run() {
   echo "== $1"; shift
   timeout -k 10 400 python3 bench.py --steps 10 --warmup 2 --no-cpu-baseline --also "" "$@" 2>/dev/null | python3 -c "
