@@ -16,7 +16,12 @@ import time
 # HIP multiplexes a process's streams onto 4 hardware queues by default, and streams that share a queue serialise.
 # A rank drives 3 call streams + the gather stream + the default stream: give every one its own queue (read by the HIP
 # runtime when it initialises, i.e. before the first torch.cuda call; measured: 4 lanes lose 15-20 % without it).
-os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
+# Several ranks: every call in flight also owns a process group whose collectives (the per-iteration survivor-count
+# all-reduce) run on that group's own RCCL stream, and the lanes' threads issue them in an order that differs from rank to
+# rank.  Collectives of different communicators may be issued in different orders only if all of them can progress
+# concurrently -- which streams that share a hardware queue cannot (a queue's packets serialise: rank A's queue holding
+# [comm 1][comm 2] against rank B's [comm 2][comm 1] would wait for each other for ever).  16 queues: one per stream.
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "16" if int(os.environ.get("WORLD_SIZE", "1")) > 1 else "8")
 
 import numpy as np
 import torch
