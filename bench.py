@@ -227,6 +227,13 @@ def main():
     # every lane's native calls run concurrently on their own threads and each holds one small all-reduce per
     # iteration: one process group (communicator) per lane, created by all ranks in the same order
     lane_groups = [dist.new_group(backend=backend) if world > 1 else None for _ in range(lanes)]
+    if world > 1:
+        # communicators are created lazily at a group's first collective (a rendezvous of all ranks): do it here, on the
+        # main thread, in the same order on every rank -- not later from the lanes' threads in whatever order they arrive
+        for g_ in lane_groups:
+            warm = torch.zeros(1, device=dev, dtype=torch.int64)
+            dist.all_reduce(warm, group=g_)
+        torch.cuda.synchronize()
 
     def make_lanes(wf_):
         out = []
