@@ -197,14 +197,16 @@ def main():
         args.scaling = "strong" if world > 1 else "weak"
     if args.frames_per_call <= 0:
         args.frames_per_call = max(8, min(32, int(round(10.24e6 / float(args.width * args.height)))))
-    per_call = max(1, min(64 // world, args.frames_per_call))
     # A unit of a native call is this rank's share of ONE frame in both modes (the frame's loop is the whole image's,
-    # cednerf/utils.py:231-235).  strong: a call holds per_call frames (total work fixed: each rank renders 1/world of
-    # every frame); weak: per_call * world frames (per-GPU work fixed: the launches keep their single-GPU size).
-    frames_per_call_of = lambda scaling: per_call * (world if scaling == "weak" else 1)
-    wf = world if args.scaling == "weak" else 1
+    # cednerf/utils.py:231-235); a call holds at most 64 frames.  strong: frames_per_call frames per call whatever the
+    # number of ranks (total work fixed: each rank renders 1/world of every frame); weak: frames_per_call * world frames
+    # (per-GPU work fixed: the launches keep their single-GPU size).
+    frames_per_call_of = lambda scaling: (max(1, min(64 // world, args.frames_per_call)) * world if scaling == "weak"
+                                          else max(1, min(64, args.frames_per_call)))
+    per_call = max(1, min(64 // world, args.frames_per_call))        # units of a one-rank call
+    fpc_main = frames_per_call_of(args.scaling)
     tdt = np.float16 if args.table_dtype == "f16" else np.float32
-    n_frames = lanes * per_call * wf
+    n_frames = lanes * fpc_main
     sc = S.make_scene(args.scene, args.width, args.height, args.regime, azim_deg=30.0, table_dtype=tdt)
     cfg = sc["cfg"]
 
@@ -215,7 +217,7 @@ def main():
         o, d = S.make_camera_rays(args.width, args.height, cfg["camera_angle_x"], c2w, cfg["opengl"])
         return {"origins": o, "viewdirs": d}
 
-    n_frames_max = lanes * per_call * world
+    n_frames_max = lanes * max(frames_per_call_of("weak"), frames_per_call_of("strong"))
     frames = [frame_rays(f) for f in range(n_frames_max if world > 1 else n_frames)]
     field = DNGPradianceField.from_params(sc["params"], dev, mlp_precision=args.mlp_precision).eval()
     field._descriptor()
@@ -235,10 +237,10 @@ def main():
             dist.all_reduce(warm, group=g_)
         torch.cuda.synchronize()
 
-    def make_lanes(wf_):
+    def make_lanes(fc_):
         out = []
         for l in range(lanes):
-            fr = frames[l * per_call * wf_:(l + 1) * per_call * wf_]
+            fr = frames[l * fc_:(l + 1) * fc_]
             r_ = cdist.ShardedRenderer(field, est, world, rank, dev, max_samples=args.max_samples, render_kwargs=rk,
                                        tile_order=os.environ.get("CED_TILE_ORDER", "1") != "0", units=per_call,
                                        schedule_group=lane_groups[l])
@@ -247,7 +249,7 @@ def main():
         return out
 
     lane_renderers, tracers = [], []
-    for l, r in enumerate(make_lanes(wf)):
+    for l, r in enumerate(make_lanes(fpc_main)):
         # HIP events around every field launch; one event set per timed step so nothing is read back
         # (hipEventElapsedTime) inside the timed region
         tracers.append([ops.FrameTracer(capacity=96, with_events=True) for _ in range(min(args.steps, 24))])
@@ -404,8 +406,8 @@ def main():
     other_scaling = None
     if world > 1:
         other = "weak" if args.scaling == "strong" else "strong"
-        wf_o = world if other == "weak" else 1
-        lanes_o = make_lanes(wf_o)
+        fc_o = frames_per_call_of(other)
+        lanes_o = make_lanes(fc_o)
         pipe_o = cdist.PipelinedRenderer(lanes_o, async_gather=True,
                                          field_max_blocks=int(os.environ.get("CED_FIELD_MAX_BLOCKS", "256")))
         pipe_o.render(ts)
@@ -420,7 +422,7 @@ def main():
         torch.cuda.synchronize()
         dist.barrier()
         d_o, s_o = reduce_window(time.perf_counter() - t_a, s_loc)
-        nf_o = lanes * per_call * wf_o
+        nf_o = lanes * fc_o
         other_scaling = {"scaling": other, "value": s_o / d_o, "unit": "samples/s", "steps": k, "frames_per_step": nf_o,
                          "rays_per_sec": nf_o * args.width * args.height * k / d_o, "ms_per_step": 1e3 * d_o / k}
         del pipe_o, lanes_o
@@ -521,9 +523,9 @@ def main():
         "config": {"workload": f"{args.scene} {args.width}x{args.height} render_image_test max_samples={args.max_samples}, "
                                f"hash L=16 F=2 T=2^21 {'fp16' if fp16 else 'fp32'} table, 64-wide MLPs, "
                                f"{args.regime} params, occupancy 128^3 x{cfg['grid_levels']}",
-                   "frames_per_step": n_frames, "frames_in_flight_per_gpu": lanes * per_call * wf,
-                   "frames_per_call": per_call * wf, "rays_per_step": n_rays_step,
-                   "parallelism": f"{lanes} call(s) in flight per GPU x {per_call * wf} frame(s) per call, every frame on the "
+                   "frames_per_step": n_frames, "frames_in_flight_per_gpu": lanes * fpc_main,
+                   "frames_per_call": fpc_main, "rays_per_step": n_rays_step,
+                   "parallelism": f"{lanes} call(s) in flight per GPU x {fpc_main} frame(s) per call, every frame on the "
                                   f"render_image_test schedule of the WHOLE image; each frame's rays tile-cyclic over "
                                   f"{world} GPU(s) (a unit of a call = one rank's share of one frame), survivor counts "
                                   f"all-reduced per iteration, one all-gather of pixels per call ({args.scaling} scaling)"},
