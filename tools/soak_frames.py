@@ -12,7 +12,7 @@ units = int(os.environ.get("UNITS", "1"))       # frames per native call (ced_re
 sc = S.make_scene("dnerf", 800, 800, "trained"); cfg = sc["cfg"]
 est = OccGridEstimator(cfg["aabb"], 128, cfg["grid_levels"]).to(dev); est.set_binaries(T(sc["binaries"]))
 rk = dict(sc["render"]); rk["render_bkgd"] = T(rk["render_bkgd"]); ts = T(sc["timestamps"])
-for prec in ("f32", "f16x2", "f16"):
+for prec in os.environ.get("MODES", "f32+h16x2,f32,f16x2,f16").split(","):
     f = DNGPradianceField.from_params(sc["params"], dev, mlp_precision=prec).eval()
     lanes, singles = [], []
     for k in range(3):
