@@ -45,6 +45,7 @@ class _HashFn(torch.autograd.Function):
     # main stream (MFMA / HBM-bound), and handed to the parameter by `join_deferred()` before the optimiser step.
     deferred = None            # None: everything on the current stream, the gradient returned through autograd
     side_blocks_per_level = 32
+    _side_cache = None         # the side stream of the last step, kept for the next
 
     @staticmethod
     def backward(ctx, dy):
@@ -79,7 +80,7 @@ class _HashFn(torch.autograd.Function):
 
 def begin_deferred_table_grad(device) -> None:
     """From now on `_HashFn.backward` runs the table gradient on a side stream; `join_deferred_table_grad` ends it."""
-    d = getattr(_HashFn, "_side_cache", None)
+    d = _HashFn._side_cache
     if d is None or d["device"] != torch.device(device):
         d = {"side": torch.cuda.Stream(device=device), "pending": [], "device": torch.device(device)}
     d["pending"].clear()
