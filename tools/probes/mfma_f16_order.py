@@ -1,0 +1,147 @@
+#!/usr/bin/env python3
+"""Operand families for tools/probes/mfma_f16_order.hip and the offline model fit of its records.
+
+    python tools/probes/mfma_f16_order.py gen  in.bin            # deterministic (seeded) operand tiles
+    tools/probes/mfma_f16_order in.bin out.bin                   # on the MI355X
+    python tools/probes/mfma_f16_order.py fit  out.bin           # here or anywhere: regenerates the inputs, scores the models
+
+A tile is A[16][32] fp16 (row, k), B[32][16] fp16 (k, col), C[16][16] fp32; the probe records D = C + A.B for four
+instruction forms (see the .hip header).  Every family below exists to separate candidate behaviours: sequential
+fp32 fma chain / exact sum rounded once / blocks of four / aligned-and-truncated adders with a few guard bits.
+"""
+import sys
+
+import numpy as np
+
+SEED = 20261005
+N_PER_FAMILY = 512
+FAMILIES = ["narrow", "wide", "very_wide", "sparse", "uniform_b_cancel", "ulp_ties", "subnormal", "one_product"]
+
+
+def rand_f16(rng, shape, emin, emax, p_zero=0.0, mant_bits=10):
+    """random fp16 values ±(1 + m/1024)·2^e, e uniform in [emin, emax] (normal range −14..15), as float32"""
+    e = rng.integers(emin, emax + 1, size=shape)
+    m = rng.integers(0, 1 << mant_bits, size=shape) << (10 - mant_bits)
+    s = rng.integers(0, 2, size=shape) * 2 - 1
+    v = s * (1.0 + m / 1024.0) * np.exp2(e.astype(np.float64))
+    if p_zero > 0:
+        v = np.where(rng.random(size=shape) < p_zero, 0.0, v)
+    h = v.astype(np.float16)
+    assert np.all(h.astype(np.float64) == v), "not representable in fp16"
+    return h
+
+
+def rand_f32(rng, shape, emin, emax, p_zero=0.0):
+    e = rng.integers(emin, emax + 1, size=shape)
+    m = rng.integers(0, 1 << 23, size=shape)
+    s = rng.integers(0, 2, size=shape) * 2 - 1
+    v = s * (1.0 + m / float(1 << 23)) * np.exp2(e.astype(np.float64))
+    if p_zero > 0:
+        v = np.where(rng.random(size=shape) < p_zero, 0.0, v)
+    return v.astype(np.float32)
+
+
+def make_tiles():
+    """-> A [n,16,32] f16, B [n,32,16] f16, C [n,16,16] f32, family id [n]"""
+    rng = np.random.default_rng(SEED)
+    As, Bs, Cs, fam = [], [], [], []
+
+    def push(a, b, c, f):
+        As.append(a.astype(np.float16)); Bs.append(b.astype(np.float16)); Cs.append(c.astype(np.float32)); fam.append(f)
+
+    for f, name in enumerate(FAMILIES):
+        for t in range(N_PER_FAMILY):
+            if name == "narrow":
+                a = rand_f16(rng, (16, 32), -1, 1); b = rand_f16(rng, (32, 16), -1, 1)
+                c = rand_f32(rng, (16, 16), -2, 6, p_zero=0.3 if t % 2 else 1.0)
+            elif name == "wide":
+                a = rand_f16(rng, (16, 32), -6, 6); b = rand_f16(rng, (32, 16), -6, 6)
+                c = rand_f32(rng, (16, 16), -14, 14, p_zero=0.2 if t % 2 else 1.0)
+            elif name == "very_wide":
+                a = rand_f16(rng, (16, 32), -14, 15); b = rand_f16(rng, (32, 16), -14, 15)
+                c = rand_f32(rng, (16, 16), -30, 30, p_zero=0.2)
+            elif name == "sparse":
+                # row i of A keeps nnz[i] entries at random k; B dense
+                a = rand_f16(rng, (16, 32), -8, 8); b = rand_f16(rng, (32, 16), -4, 4)
+                keep = np.zeros((16, 32), bool)
+                for i in range(16):
+                    nnz = (1, 2, 2, 2, 3, 3, 4, 5, 8, 2, 3, 2, 4, 2, 3, 6)[i]
+                    keep[i, rng.choice(32, nnz, replace=False)] = True
+                a = np.where(keep, a, np.float16(0))
+                c = rand_f32(rng, (16, 16), -10, 10, p_zero=0.5)
+            elif name == "uniform_b_cancel":
+                # B[k][j] = y_j for every k: products of row i are a[i][k]·y_j, so ±x pairs in A cancel exactly
+                y = rand_f16(rng, (1, 16), -3, 3); b = np.repeat(y, 32, axis=0)
+                a = np.zeros((16, 32), np.float16)
+                for i in range(16):
+                    ks = rng.choice(32, 6, replace=False)
+                    big = rand_f16(rng, (), 4, 10)
+                    a[i, ks[0]] = big; a[i, ks[1]] = -big
+                    n_small = rng.integers(1, 5)
+                    a[i, ks[2:2 + n_small]] = rand_f16(rng, (n_small,), -14, -2)
+                c = rand_f32(rng, (16, 16), -20, 4, p_zero=0.5)
+            elif name == "ulp_ties":
+                # C in [2^E, 2^(E+1)); products are ±2^(E-23-q), q in 0..4: fractions of an ulp of C at a few k
+                E = int(rng.integers(-2, 10))
+                b = np.ones((32, 16), np.float16)
+                a = np.zeros((16, 32), np.float64)
+                for i in range(16):
+                    nnz = int(rng.integers(1, 7))
+                    ks = rng.choice(32, nnz, replace=False)
+                    q = rng.integers(0, 5, size=nnz)
+                    sg = rng.integers(0, 2, size=nnz) * 2 - 1
+                    a[i, ks] = sg * np.exp2(E - 23.0 - q)
+                # split 2^(E-23-q) over a and b so that both stay in the fp16 normal range
+                sh = (E - 23) // 2
+                a = a * np.exp2(-sh)
+                b = b * np.float16(np.exp2(sh))
+                a = a.astype(np.float16)
+                m = rng.integers(0, 1 << 23, size=(16, 16))
+                c = ((1.0 + m / float(1 << 23)) * np.exp2(float(E))).astype(np.float32)
+                c = np.where(rng.random((16, 16)) < 0.3, -c, c)
+            elif name == "subnormal":
+                a = rand_f16(rng, (16, 32), -14, -8)
+                sub = (rng.integers(1, 1024, size=(16, 32)) * 2.0 ** -24).astype(np.float16)     # fp16 subnormals
+                a = np.where(rng.random((16, 32)) < 0.5, sub * (rng.integers(0, 2, size=(16, 32)) * 2 - 1).astype(np.float16), a)
+                b = rand_f16(rng, (32, 16), -14, 2)
+                subb = (rng.integers(1, 1024, size=(32, 16)) * 2.0 ** -24).astype(np.float16)
+                b = np.where(rng.random((32, 16)) < 0.3, subb, b)
+                c = rand_f32(rng, (16, 16), -60, -20, p_zero=0.5)
+                if t % 4 == 0:   # fp32-subnormal accumulators beside zero products
+                    c = (rng.integers(-(1 << 22), 1 << 22, size=(16, 16)).astype(np.float64) * 2.0 ** -149).astype(np.float32)
+                    a = np.where(rng.random((16, 32)) < 0.9, np.float16(0), a)
+            elif name == "one_product":
+                # exactly one non-zero product per row, k swept over rows and tiles: c + p with every rounding case
+                a = np.zeros((16, 32), np.float16)
+                for i in range(16):
+                    a[i, (t * 16 + i) % 32] = rand_f16(rng, (), -4, 4)
+                b = rand_f16(rng, (32, 16), -4, 4)
+                c = rand_f32(rng, (16, 16), -6, 12)
+            push(a, b, c, f)
+    return np.stack(As), np.stack(Bs), np.stack(Cs), np.array(fam)
+
+
+def cmd_gen(path):
+    A, B, C, _ = make_tiles()
+    n = A.shape[0]
+    with open(path, "wb") as f:
+        f.write(np.int32(n).tobytes())
+        for t in range(n):
+            f.write(A[t].view(np.uint16).tobytes()); f.write(B[t].view(np.uint16).tobytes()); f.write(C[t].tobytes())
+    print(f"{n} tiles -> {path}")
+
+
+def load_out(path):
+    raw = np.fromfile(path, dtype=np.uint8)
+    n = int(raw[:4].view(np.int32)[0])
+    return raw[4:].view(np.float32).reshape(n, 4, 16, 16)
+
+
+if __name__ == "__main__":
+    if len(sys.argv) >= 3 and sys.argv[1] == "gen":
+        cmd_gen(sys.argv[2])
+    elif len(sys.argv) >= 3 and sys.argv[1] == "fit":
+        from mfma_f16_models import fit_all      # noqa: E402  (kept apart: the models are the long part)
+        fit_all(make_tiles(), load_out(sys.argv[2]))
+    else:
+        print(__doc__)
