@@ -8,10 +8,11 @@
 //       reference's tiny-cuda-nn FullyFusedMLP (cednerf/model.py:200-222,280-309) and of
 //       BASELINE config 5 ("fp16 hash features + fp16 MFMA MLP").
 //
-// Outside the GEMMs the encodings (Frequency / SH / time), the hash-grid gather and its interpolation are the
-// same fp32 code as the exact kernel (field_device.hpp), and so is the position normalisation (one ulp there is
-// amplified by the fine hash levels); exp / sigmoid / tanh and the direction normalisation use the hardware's
-// 1-ulp exp2, reciprocal and rsqrt (field_half_device.hpp).
+// Outside the GEMMs everything is the same deterministic fp32 code as the exact kernel (field_device.hpp, det_expf,
+// IEEE division / square root): encodings (Frequency / SH / time), hash-grid gather and interpolation, position
+// normalisation, trunc_exp, tanh, sigmoid.  Together with the CPU model of the matrix instruction
+// (oracle/mfma_f16_model.h: two blocks of eight products per v_mfma_f32_16x16x16_f16, each cut below
+// 2^(Emax - 24) and rounded once) every output of these kernels is reproducible on the CPU bit for bit.
 //
 // Geometry: D^T = W * X^T as in field.hip, but K = 32 per product block (mfma_k32, field_half_device.hpp): lane (g = lane>>4, c = lane&15) supplies
 // inputs 32ks + 8g + e (e = 0..7, four packed VGPRs) of sample c, and receives accumulator rows 4g + r.
@@ -168,8 +169,8 @@ __global__ __launch_bounds__(THREADS) void field_half_kernel(FieldArgs A)
                 if (A.use_div) {
                     constexpr int kFineReg[3] = { 3, 0, 1 };          // rows 3,4,5: (g0,r3), (g1,r0), (g1,r1)
                     const float fine = __shfl(D[j][0][kFineReg[a]], (a == 0) ? c : 16 + c, 64);
-                    const float e = fast_exp(2.0f * fine);
-                    const float th = 1.0f - 2.0f * fast_rcp(e + 1.0f);
+                    const float e = det_expf(2.0f * fine);
+                    const float th = 1.0f - 2.0f / (e + 1.0f);
                     m = m + th * A.moving_step;
                 }
                 mv[a] = m;
@@ -236,7 +237,7 @@ __global__ __launch_bounds__(THREADS) void field_half_kernel(FieldArgs A)
 #pragma unroll
         for (int j = 0; j < NT; ++j) {
             const int64_t s = tile * TILE + 16 * j + c;
-            float sg = fast_exp(D[j][0][3] - 1.0f);            // trunc_exp(raw - 1) * selector
+            float sg = det_expf(D[j][0][3] - 1.0f);            // trunc_exp(raw - 1) * selector
             sg = sel[j] ? sg : 0.0f;
             if (g == 3 && s < n_eff) A.sigma[sbase + s] = sg;
             if (A.geo && s < n_eff) {
@@ -254,17 +255,13 @@ __global__ __launch_bounds__(THREADS) void field_half_kernel(FieldArgs A)
 #pragma unroll
                 for (int a = 0; a < 3; ++a)
                     dv[a] = A.rays_mode ? A.rays_d[3 * ridx[j] + a] : A.dir[3 * sidx[j] + a];
-                const float inv_nrm = __builtin_amdgcn_rsqf((dv[0] * dv[0] + dv[1] * dv[1]) + dv[2] * dv[2]);
-                float v[3];
-#pragma unroll
-                for (int a = 0; a < 3; ++a) {
-                    const float u = (dv[a] * inv_nrm + 1.0f) / 2.0f;
-                    v[a] = u * 2.0f - 1.0f;
-                }
-                float sh = 0.28209479177387814f;
-                sh = (g == 1) ? (-0.48860251190291987f * v[1]) : sh;
-                sh = (g == 2) ? (0.48860251190291987f * v[2]) : sh;
-                sh = (g == 3) ? (-0.48860251190291987f * v[0]) : sh;
+                const float nrm = __builtin_sqrtf((dv[0] * dv[0] + dv[1] * dv[1]) + dv[2] * dv[2]);
+                // lane group g feeds SH coefficient g: only that direction component is normalised (as field_kernel.hpp)
+                const float comp = (g == 1) ? dv[1] : (g == 2) ? dv[2] : dv[0];
+                const float u = (comp / nrm + 1.0f) / 2.0f;
+                const float vv = u * 2.0f - 1.0f;
+                const float coef = (g == 2) ? 0.48860251190291987f : -0.48860251190291987f;
+                const float sh = (g == 0) ? 0.28209479177387814f : coef * vv;
                 float hin[8];
                 hin[0] = sh;
 #pragma unroll
@@ -281,14 +278,9 @@ __global__ __launch_bounds__(THREADS) void field_half_kernel(FieldArgs A)
 #pragma unroll
             for (int j = 0; j < NT; ++j) {
                 const int64_t s = tile * TILE + 16 * j + c;
-                float o3[3];
-#pragma unroll
-                for (int a = 0; a < 3; ++a) o3[a] = fast_rcp(1.0f + fast_exp(-D[j][0][a]));
-                if (g == 0 && s < n_eff) {
-                    A.rgb[3 * (sbase + s)] = o3[0];
-                    A.rgb[3 * (sbase + s) + 1] = o3[1];
-                    A.rgb[3 * (sbase + s) + 2] = o3[2];
-                }
+                // the packer put colour channel a on accumulator row 4a = (lane group a, register 0): one sigmoid per lane
+                const float o1 = 1.0f / (1.0f + det_expf(-D[j][0][0]));
+                if (g < 3 && s < n_eff) A.rgb[3 * (sbase + s) + g] = o1;
             }
         }
     }
@@ -307,6 +299,7 @@ void pack_half_layer(const float *w, int n_out, int n_in, int nb, int ks, int fr
         int neuron = p;
         if (row_map == HALF_ROW_HIDDEN) neuron = half_hidden_neuron(p);
         else if (row_map == HALF_ROW_BASE_OUT) neuron = half_base_out_neuron(p);
+        else if (row_map == HALF_ROW_RGB) neuron = (p % 4 == 0) ? p / 4 : n_out;
         if (neuron >= n_out) continue;
         for (int k = 0; k < ks * 32; ++k) {
             const int g = (k % 32) / 8, e = k % 8;
@@ -418,7 +411,7 @@ extern "C" int ced_pack_field_weights_half(int use_div_offsets, int time_mode, i
         { m_w2, 64, 64, 4, 2, fr[2], HALF_ROW_HIDDEN, HALF_COL_NATURAL },   { m_w3, n_mo, 64, 1, 2, fr[3], HALF_ROW_NATURAL, HALF_COL_NATURAL },
         { b_w0, 64, base_in, 4, ksb0, fr[4], HALF_ROW_HIDDEN, HALF_COL_HASH }, { b_w1, 16, 64, 1, 2, fr[5], HALF_ROW_BASE_OUT, HALF_COL_NATURAL },
         { h_w0, 64, 19, 4, 1, fr[6], HALF_ROW_HIDDEN, HALF_COL_HEAD },      { h_w1, 64, 64, 4, 2, fr[7], HALF_ROW_HIDDEN, HALF_COL_NATURAL },
-        { h_w2, 3, 64, 1, 2, fr[8], HALF_ROW_NATURAL, HALF_COL_NATURAL },
+        { h_w2, 3, 64, 1, 2, fr[8], HALF_ROW_RGB, HALF_COL_NATURAL },
     };
     for (const L &l : layers) pack_half_layer(l.w, l.n_out, l.n_in, l.nb, l.ks, l.frag, l.row, l.col, hi, split ? lo : nullptr);
     return CED_OK;

@@ -28,20 +28,25 @@ constexpr float kHalfMax = 65504.0f;
 #define CED_HALF_MFMA_GUARD 3
 #endif
 
-// Elementwise math of the half-precision kernels: the hardware's 1-ulp exp2 / reciprocal / rsqrt instead of the
-// exact kernel's deterministic polynomials and IEEE divisions (those exist to match the oracle bit for bit, which
-// these modes do not attempt; the differences are ~1e-7 relative, far below the fp16 operand rounding).
-__device__ __forceinline__ float fast_exp(float x) { return __builtin_amdgcn_exp2f(x * 1.44269504088896340736f); }
-__device__ __forceinline__ float fast_rcp(float x) { return __builtin_amdgcn_rcpf(x); }
+// Elementwise math of the half-precision kernels: since round 4 the SAME deterministic forms as the exact kernel
+// (det_expf, IEEE division and square root).  With the matrix instruction's own summation restated on the CPU
+// (oracle/mfma_f16_model.h) that makes these modes bit-comparable with the oracle's fp16-operand modes: sigma,
+// hence every sample count, opacity and depth -- and rgb.  (Rounds 1-3 used the hardware's 1-ulp exp2 / reciprocal /
+// rsqrt here: 2-3 % faster, not reproducible on a CPU.)
 
 // eight fp32 values -> packed fp16 operand (and the fp16 remainder in F16X2 mode)
 template <bool SPLIT> __device__ __forceinline__ void to_half8(const float (&v)[8], h8 &hi, h8 &lo)
 {
 #pragma unroll
     for (int e = 0; e < 8; ++e) {
-        const _Float16 h = (_Float16)v[e];
+        // The value is made opaque first: left visible, hipcc folds a producing multiply / fma into the conversion
+        // (v_fma_mixlo_f16), which rounds ONCE to fp16 instead of to fp32 and then to fp16 -- a different result
+        // whenever the fp32 value is an fp16 tie (found in round 4: the SH inputs of the f16 kernels, 1 value in 8192).
+        float x = v[e];
+        asm("" : "+v"(x));
+        const _Float16 h = (_Float16)x;
         hi[e] = h;
-        if constexpr (SPLIT) lo[e] = (_Float16)(v[e] - (float)h);
+        if constexpr (SPLIT) lo[e] = (_Float16)(x - (float)h);
     }
 }
 
@@ -137,7 +142,8 @@ __device__ __forceinline__ void to_operand_h(const f4 (&D)[NT][4], h8 (&Bh)[NT][
 }
 
 // host: one layer W[n_out][n_in] into 16x16x32 A-fragment order at fragment `frag` (see field_half.hip)
-enum HalfRowMap { HALF_ROW_NATURAL, HALF_ROW_HIDDEN, HALF_ROW_BASE_OUT };
+// HALF_ROW_RGB: colour channel a on accumulator row 4a = (lane group a, register 0): one sigmoid per lane
+enum HalfRowMap { HALF_ROW_NATURAL, HALF_ROW_HIDDEN, HALF_ROW_BASE_OUT, HALF_ROW_RGB };
 enum HalfColMap { HALF_COL_NATURAL, HALF_COL_HASH, HALF_COL_HEAD };
 void pack_half_layer(const float *w, int n_out, int n_in, int nb, int ks, int frag, int row_map, int col_map,
                      _Float16 *hi, _Float16 *lo);

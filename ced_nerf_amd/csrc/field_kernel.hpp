@@ -396,9 +396,9 @@ __global__ __launch_bounds__(THREADS) void field_kernel(FieldArgs A)
 #pragma unroll
                     for (int a = 0; a < 3; ++a)
                         dv[a] = A.rays_mode ? A.rays_d[3 * ridx[j] + a] : A.dir[3 * sidx[j] + a];
-                    const float inv_nrm = __builtin_amdgcn_rsqf((dv[0] * dv[0] + dv[1] * dv[1]) + dv[2] * dv[2]);
+                    const float nrm = __builtin_sqrtf((dv[0] * dv[0] + dv[1] * dv[1]) + dv[2] * dv[2]);
                     const float comp = (g == 1) ? dv[1] : (g == 2) ? dv[2] : dv[0];
-                    const float u = (comp * inv_nrm + 1.0f) / 2.0f;
+                    const float u = (comp / nrm + 1.0f) / 2.0f;
                     const float vv = u * 2.0f - 1.0f;
                     const float coef = (g == 2) ? 0.48860251190291987f : -0.48860251190291987f;
                     float hin[8];
@@ -416,18 +416,13 @@ __global__ __launch_bounds__(THREADS) void field_kernel(FieldArgs A)
                 mlp_layer_h<2, 1, NT, true>(hw + BL::HF_H2 * kFragHalves, hwl + BL::HF_H2 * kFragHalves, lane, Bh, Bl, D);
 #pragma unroll
                 for (int j = 0; j < NT; ++j) {
-                    // colour channel a = accumulator row a: lane group 0, register a
-                    float o3[3];
-#pragma unroll
-                    for (int a = 0; a < 3; ++a) o3[a] = fast_rcp(1.0f + fast_exp(-D[j][0][a]));
+                    // the packer put colour channel a on accumulator row 4a = (lane group a, register 0)
+                    const float o1 = 1.0f / (1.0f + det_expf(-D[j][0][0]));
                     int lane_now = (int)threadIdx.x;
                     asm volatile("" : "+v"(lane_now));
+                    const int g_now = (lane_now >> 4) & 3;
                     const int64_t s_now = tile * TILE + 16 * j + (lane_now & 15);
-                    if (((lane_now >> 4) & 3) == 0 && s_now < n_eff) {
-                        A.rgb[3 * (sbase + s_now)] = o3[0];
-                        A.rgb[3 * (sbase + s_now) + 1] = o3[1];
-                        A.rgb[3 * (sbase + s_now) + 2] = o3[2];
-                    }
+                    if (g_now < 3 && s_now < n_eff) A.rgb[3 * (sbase + s_now) + g_now] = o1;
                 }
             }
             continue;

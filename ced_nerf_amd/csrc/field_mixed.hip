@@ -91,6 +91,6 @@ extern "C" int ced_pack_field_weights_mixed(int use_div_offsets, int time_mode, 
     _Float16 *lo = hi + Blob<false>::HEAD_FRAGS * kFragHalves;
     pack_half_layer(h_w0, 64, 19, 4, 1, Blob<false>::HF_H0, HALF_ROW_HIDDEN, HALF_COL_HEAD, hi, lo);
     pack_half_layer(h_w1, 64, 64, 4, 2, Blob<false>::HF_H1, HALF_ROW_HIDDEN, HALF_COL_NATURAL, hi, lo);
-    pack_half_layer(h_w2, 3, 64, 1, 2, Blob<false>::HF_H2, HALF_ROW_NATURAL, HALF_COL_NATURAL, hi, lo);
+    pack_half_layer(h_w2, 3, 64, 1, 2, Blob<false>::HF_H2, HALF_ROW_RGB, HALF_COL_NATURAL, hi, lo);
     return CED_OK;
 }

@@ -25,8 +25,8 @@ MAX_LEVELS = 16
 
 def build(force: bool = False) -> str:
     """Compile the C oracle with the committed Makefile (gcc)."""
-    src = os.path.join(_HERE, "cednerf_oracle.c")
-    if force or not os.path.exists(_LIB_PATH) or os.path.getmtime(_LIB_PATH) < os.path.getmtime(src):
+    srcs = [os.path.join(_HERE, f) for f in ("cednerf_oracle.c", "mfma_f16_model.h", "Makefile")]
+    if force or not os.path.exists(_LIB_PATH) or os.path.getmtime(_LIB_PATH) < max(os.path.getmtime(f) for f in srcs):
         subprocess.check_call(["make", "-C", _HERE, "-B"], stdout=subprocess.DEVNULL)
     return _LIB_PATH
 
@@ -47,7 +47,7 @@ class _FieldT(C.Structure):
         ("m_w0", C.c_void_p), ("m_w1", C.c_void_p), ("m_w2", C.c_void_p), ("m_w3", C.c_void_p),
         ("b_w0", C.c_void_p), ("b_w1", C.c_void_p),
         ("h_w0", C.c_void_p), ("h_w1", C.c_void_p), ("h_w2", C.c_void_p),
-        ("hash", _HashT), ("mlp_half", C.c_int32), ("reserved", C.c_int32),
+        ("hash", _HashT), ("mlp_half", C.c_int32), ("reserved", C.c_int32), ("half_cache", C.c_void_p),
     ]
 
 
@@ -115,9 +115,13 @@ def hash_levels(base_res: int = 16, max_res: int = 1024, n_levels: int = 16, log
 class OracleField:
     """DNGPradianceField (cednerf/model.py:97-488) evaluated by the C oracle."""
 
-    def __init__(self, params: Dict, mlp_half: bool = False):
-        """mlp_half: the fp16-operand / fp32-accumulate MLP class (tcnn FullyFusedMLP): weights are
-        rounded to fp16 here, layer inputs inside the C code."""
+    MLP_MODES = {"f32": 0, "f16": 1, "f16x2": 2, "f32+h16x2": 3}
+
+    def __init__(self, params: Dict, mlp_half=False, prepare: bool = True):
+        """mlp_half: MLP arithmetic -- False / "f32": fp32 fmaf chains; True / "f16": the fp16-operand / fp32-accumulate
+        class (tcnn FullyFusedMLP, SURVEY A.8) as gfx950's matrix instruction computes it (mfma_f16_model.h);
+        "f16x2": operands split into two fp16 numbers; "f32+h16x2": only mlp_head split.  Weights are passed in fp32
+        and rounded / split inside the C code."""
         self.p = params
         h = params["hash"]
         self.levels = hash_levels(h["base_res"], h["max_res"], h["n_levels"], h["log2_hashmap_size"])
@@ -149,8 +153,9 @@ class OracleField:
         ft.use_div_offsets = int(bool(params["use_div_offsets"]))
         ft.time_mode = int(params["time_mode"])
         ft.base_in = 41 if ft.time_mode else 32
-        rw = (lambda w: _f32(_f32(w).astype(np.float16))) if mlp_half else _f32
-        ft.mlp_half = int(bool(mlp_half))
+        rw = _f32
+        ft.mlp_half = self.MLP_MODES[mlp_half] if isinstance(mlp_half, str) else int(mlp_half)
+        assert ft.mlp_half in (0, 1, 2, 3), mlp_half
         m = [rw(w) for w in params["xyz_wrap"]]
         b = [rw(w) for w in params["mlp_base"]]
         hd = [rw(w) for w in params["mlp_head"]]
@@ -163,7 +168,18 @@ class OracleField:
         ft.b_w0, ft.b_w1 = [w.ctypes.data for w in b]
         ft.h_w0, ft.h_w1, ft.h_w2 = [w.ctypes.data for w in hd]
         ft.hash = ht
+        ft.half_cache = None
         self.field_t = ft
+        if ft.mlp_half and prepare:
+            lib().ced_o_field_prepare(C.byref(ft))
+
+    def __del__(self):
+        ft = getattr(self, "field_t", None)
+        if ft is not None and ft.half_cache:
+            try:
+                lib().ced_o_field_release(C.byref(ft))
+            except Exception:
+                pass
 
     # hash_encoder(x) -- model.py:384
     def hash_encode(self, x: np.ndarray, t: Optional[np.ndarray] = None) -> np.ndarray:

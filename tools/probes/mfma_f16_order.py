@@ -15,7 +15,12 @@ import numpy as np
 
 SEED = 20261005
 N_PER_FAMILY = 512
-FAMILIES = ["narrow", "wide", "very_wide", "sparse", "uniform_b_cancel", "ulp_ties", "subnormal", "one_product"]
+FAMILIES = ["narrow", "wide", "very_wide", "sparse", "uniform_b_cancel", "ulp_ties", "subnormal", "one_product",
+            # second set (appended: the records of the first eight keep their tiles)
+            "phantom_zero", "relu_like", "big_c", "signed_zero",
+            # third set: accumulators a few thousand ulps from a power of two, products 2^-9..2^-13 of them: sums that carry
+            # into the next binade or cancel into the one below (the final rounding sees 8 bits below the RESULT's last place)
+            "binade_crossing"]
 
 
 def rand_f16(rng, shape, emin, emax, p_zero=0.0, mant_bits=10):
@@ -117,6 +122,46 @@ def make_tiles():
                     a[i, (t * 16 + i) % 32] = rand_f16(rng, (), -4, 4)
                 b = rand_f16(rng, (32, 16), -4, 4)
                 c = rand_f32(rng, (16, 16), -6, 12)
+            elif name == "phantom_zero":
+                # zero operands beside LARGE partners: if a zero's exponent field took part in Emax, the few real (tiny)
+                # products of the row would be cut far above their bits
+                a = np.zeros((16, 32), np.float16)
+                b = rand_f16(rng, (32, 16), 10, 15)
+                tiny_b = rand_f16(rng, (32, 16), -14, -8)
+                for i in range(16):
+                    ks = rng.choice(32, int(rng.integers(1, 4)), replace=False)
+                    a[i, ks] = rand_f16(rng, (len(ks),), -14, -10)
+                    b[ks, :] = tiny_b[ks, :] if t % 2 == 0 else b[ks, :]
+                if t % 3 == 0:      # and the mirrored case: zeros in B beside large A
+                    a = np.where(a == 0, rand_f16(rng, (16, 32), 10, 15), a)
+                    zero_rows = rng.random((32, 1)) < 0.7
+                    b = np.where(zero_rows, np.float16(0), tiny_b)
+                c = rand_f32(rng, (16, 16), -44, -18, p_zero=0.5)
+            elif name == "relu_like":
+                # the MLP's own regime: weights 2^-6..1, activations half zero, the rest 2^-10..8, running sums as C
+                a = rand_f16(rng, (16, 32), -6, 0)
+                b = rand_f16(rng, (32, 16), -10, 3, p_zero=0.5)
+                if t % 2:           # remainder-like operands (the lo parts of the split mode)
+                    b = rand_f16(rng, (32, 16), -22 + 8, -8, p_zero=0.3)
+                c = rand_f32(rng, (16, 16), -8, 5, p_zero=0.2)
+            elif name == "big_c":
+                a = rand_f16(rng, (16, 32), -4, 4); b = rand_f16(rng, (32, 16), -4, 4)
+                c = rand_f32(rng, (16, 16), 10, 60)
+            elif name == "signed_zero":
+                a = rand_f16(rng, (16, 32), -2, 2, p_zero=0.6); b = rand_f16(rng, (32, 16), -2, 2, p_zero=0.3)
+                a = np.where((a == 0) & (rng.random((16, 32)) < 0.5), np.float16(-0.0), a)
+                c = np.where(rng.random((16, 16)) < 0.5, np.float32(-0.0), np.float32(0.0))
+                if t % 2:           # exact cancellation to zero: +x*y - x*y
+                    a[:, 16:] = -a[:, :16]; b[16:, :] = b[:16, :]
+                    a[:, 8:16] = -a[:, :8]; b[8:16, :] = b[:8, :]
+            elif name == "binade_crossing":
+                E = int(rng.integers(-8, 5))
+                a = rand_f16(rng, (16, 32), -4, -1, p_zero=0.3)
+                b = rand_f16(rng, (32, 16), max(E - 13, -14), max(E - 9, -12), p_zero=0.2)
+                m = rng.integers(0, 1 << 13, size=(16, 16))
+                below = rng.random((16, 16)) < 0.5                      # just below 2^(E+1) / just above 2^E
+                c = np.where(below, (2.0 - m * 2.0 ** -23), (1.0 + m * 2.0 ** -23)) * 2.0 ** E
+                c = (c * (rng.integers(0, 2, size=(16, 16)) * 2 - 1)).astype(np.float32)
             push(a, b, c, f)
     return np.stack(As), np.stack(Bs), np.stack(Cs), np.array(fam)
 
