@@ -344,7 +344,14 @@ class PipelinedRenderer:
                                 before_frame(i, step)
                         else:
                             before_frame(i, step)
-                    ts = timestamps(i, step) if callable(timestamps) else timestamps
+                    if callable(timestamps) and self.streams[i] is not None:
+                        # on the lane's stream, like everything else of the frame: a tensor the callable BUILDS (e.g. the
+                        # concatenated times of a call's frames, video.render_video) would otherwise be produced on this
+                        # thread's default stream, which nothing orders before the lane's kernels that read it
+                        with torch.cuda.stream(self.streams[i]):
+                            ts = timestamps(i, step)
+                    else:
+                        ts = timestamps(i, step) if callable(timestamps) else timestamps
                     done[step][i].put(self._lane(i, ts))
             except BaseException as e:           # hand the failure to the collecting thread instead of leaving it waiting
                 for s in range(step, n_steps):
