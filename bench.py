@@ -2,10 +2,17 @@
 
 One frame = one full-frame `render_image_test` (cednerf/utils.py:153-318) of the BASELINE.json
 config-2 workload: 800x800 D-NeRF "lego"-shaped synthetic scene, hash L=16 F=2 T=2^21 fp32 table,
-64-wide MLPs, "trained-like" parameters, max_samples=1024.  A step renders 3 calls in flight x 8 frames
-per call x N GPUs such frames (consecutive camera azimuths of a video render), every frame on its own
-render_image_test schedule; with N GPUs their rays are dealt tile-cyclically over the ranks and the pixels
-are all-gathered over RCCL, so per-GPU work is fixed (weak scaling).
+64-wide MLPs, "trained-like" parameters, max_samples=1024.  A step renders 3 calls in flight x 16 frames
+per call (consecutive camera azimuths of a video render), every frame on its own render_image_test
+schedule.  With N GPUs every frame's rays are dealt tile-cyclically over the ranks under the ONE
+image-global schedule (survivor counts all-reduced per iteration) and the pixels are all-gathered over
+RCCL: the frames of a step are fixed, so the default is STRONG scaling (value(N) / value(1) is the speed-up;
+--scaling weak renders that many frames per GPU instead).
+
+Default arithmetic since round 4: f16x2 -- all three MLPs on fp16 MFMA with every operand split into two fp16 numbers --
+because it now meets both bars: sample counts / opacity / depth / rgb BIT-IDENTICAL to the CPU oracle's mode of the same
+name (the oracle restates the matrix instruction, oracle/mfma_f16_model.h) and within 1e-4 of the plain fp32 oracle
+with the same sample counts.
 """
 import argparse
 import json
@@ -14,14 +21,11 @@ import sys
 import time
 
 # HIP multiplexes a process's streams onto 4 hardware queues by default, and streams that share a queue serialise.
-# A rank drives 3 call streams + the gather stream + the default stream: give every one its own queue (read by the HIP
-# runtime when it initialises, i.e. before the first torch.cuda call; measured: 4 lanes lose 15-20 % without it).
-# Several ranks: every call in flight also owns a process group whose collectives (the per-iteration survivor-count
-# all-reduce) run on that group's own RCCL stream, and the lanes' threads issue them in an order that differs from rank to
-# rank.  Collectives of different communicators may be issued in different orders only if all of them can progress
-# concurrently -- which streams that share a hardware queue cannot (a queue's packets serialise: rank A's queue holding
-# [comm 1][comm 2] against rank B's [comm 2][comm 1] would wait for each other for ever).  16 queues: one per stream.
-os.environ.setdefault("GPU_MAX_HW_QUEUES", "16" if int(os.environ.get("WORLD_SIZE", "1")) > 1 else "8")
+# A rank drives 3 call streams + the gather stream + the default stream (+ RCCL's own): give every one its own queue (read by
+# the HIP runtime when it initialises, i.e. before the first torch.cuda call; measured: 4 lanes lose 15-20 % without it).
+# A matter of speed only: since round 4 every collective of a rank is issued by ONE thread on ONE communicator in an order
+# that cannot differ between ranks (ced_nerf_amd/dist.py: PipelinedRenderer), so liveness no longer depends on queues.
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
 
 import numpy as np
 import torch
@@ -49,16 +53,19 @@ def parse():
     ap.add_argument("--height", type=int, default=800)
     ap.add_argument("--scene", default="dnerf", choices=["dnerf", "hypernerf", "dynerf"])
     ap.add_argument("--table-dtype", default="f32", choices=["f32", "f16"])
-    ap.add_argument("--also", default="f32,f16x2,f16",
+    ap.add_argument("--also", default="f32+h16x2,f32,f16",
                     help="comma list of further --mlp-precision modes to time briefly after the main measurement "
                          "(reported under other_mlp_precisions; empty string: none)")
-    ap.add_argument("--mlp-precision", default="f32+h16x2", choices=["f32+h16x2", "f32", "f16x2", "f16"],
-                    help="arithmetic of the three MLPs (include/cednerf_hip.h CED_MLP_*): f32+h16x2 (default) = the chain "
-                         "that decides sample counts, opacity and depth (xyz_wrap, hash features, mlp_base, exp) exact "
-                         "fp32 MFMA, bit-identical to the CPU oracle, and only mlp_head (rgb) on split-fp16 MFMA with "
-                         "fp32 accumulation: counts / opacity / depth bit-exact, rgb <= 1e-4 (the north-star's bar); "
-                         "f32 = all three MLPs exact (rgb bit-exact too); f16x2 = all on split-fp16 (<= 1e-4 on pixels, "
-                         "counts within 1e-5); f16 = fp16 operands, the reference's tcnn class")
+    ap.add_argument("--mlp-precision", default="f16x2", choices=["f32+h16x2", "f32", "f16x2", "f16"],
+                    help="arithmetic of the three MLPs (include/cednerf_hip.h CED_MLP_*); every mode is bit-identical to the "
+                         "CPU oracle's mode of the same name (tests).  f16x2 (default) = all three on fp16 MFMA, every operand "
+                         "split into two fp16 numbers, fp32 accumulate: within 1e-4 of the plain fp32 oracle, same sample "
+                         "counts; f32+h16x2 = the chain that decides counts / opacity / depth on exact fp32 MFMA (those three "
+                         "bit-identical to the PLAIN oracle), only mlp_head split; f32 = all exact fp32 MFMA; f16 = fp16 "
+                         "operands, the reference's tcnn class (BASELINE config 5 with --table-dtype f16)")
+    ap.add_argument("--comm-timeout", type=float, default=float(os.environ.get("CED_COMM_TIMEOUT_S", "120")),
+                    help="deadline (s) of every wait of the multi-rank exchange and of the process group's collectives: a "
+                         "stuck run prints which lane / step / iteration it waits for and exits with status 3")
     ap.add_argument("--pmc-json", default=None,
                     help="per-launch HBM traffic of the field kernel from the rocprofv3 --pmc passes (tools/pmc_summary.py)")
     ap.add_argument("--regime", default="trained")
@@ -88,6 +95,9 @@ def parse():
                     help="skip the one-frame-alone latency measurement after the timed region (profiling runs: every "
                          "field launch of the process is then one of the timed kind)")
     ap.add_argument("--cpu-stride", type=int, default=1, help="pixel stride of the CPU-baseline ray sample")
+    ap.add_argument("--oracle-mode-stride", type=int, default=2,
+                    help="pixel stride of the ray set on which the timed mode is compared BIT FOR BIT with the oracle's mode of "
+                         "the same name (parity_vs_oracle_mode; 0 = skip, 1 = the whole frame: minutes of host time)")
     ap.add_argument("--cpu-passes", type=int, default=3, help="how many times the CPU baseline renders its sample")
     ap.add_argument("--torch-stride", type=int, default=4,
                     help="pixel stride of the ray sample the PyTorch-fp32 CPU path renders (0 = skip)")
@@ -111,6 +121,7 @@ def cpu_baseline(sc, args):
     dt = (time.perf_counter() - t0) / args.cpu_passes
     cores = int(os.environ["OMP_NUM_THREADS"])
     return {"value": out[3] / dt, "unit": "samples/s", "cores": cores, "kind": "port",
+            "implementation": "C port (oracle/cednerf_oracle.c: scalar C, OpenMP over rays, plain fp32 arithmetic)",
             "rays_per_sec": o.shape[0] * o.shape[1] / dt,
             "sample": f"{args.cpu_passes} passes over every {s}th pixel in x and y of the same "
                       f"{args.width}x{args.height} frame ({o.shape[0] * o.shape[1]} rays, {out[3]} samples, "
@@ -138,6 +149,31 @@ def parity_vs_oracle(oracle_out, gpu_single, gpu_timed_frame0, mode):
     return out
 
 
+def parity_vs_oracle_mode(sc, args, field, est, rk, ts, T, mode, stride=2):
+    """The timed arithmetic mode against the oracle's mode of the SAME name, bit for bit: every `stride`-th pixel in x and
+    y of frame 0 rendered as an image of its own (render_image_test's schedule is image-global, so both sides render the
+    same strided ray set) by the HIP path and by the oracle (which restates the matrix instruction: minutes of host time
+    for a full frame, hence the stride)."""
+    from oracle import oracle as O
+    from ced_nerf_amd.utils import Rays, render_image_test
+    cfg = sc["cfg"]
+    of = O.OracleField(sc["params"], mlp_half=mode)
+    oest = O.OracleEstimator(cfg["aabb"], cfg["grid_resolution"], cfg["grid_levels"], sc["binaries"])
+    o = np.ascontiguousarray(sc["origins"][::stride, ::stride]); d = np.ascontiguousarray(sc["viewdirs"][::stride, ::stride])
+    t0 = time.perf_counter()
+    want = O.render_image_test(args.max_samples, of, oest, o, d, timestamps=sc["timestamps"], **sc["render"])
+    dt = time.perf_counter() - t0
+    got = render_image_test(args.max_samples, field, est, Rays(T(o), T(d)), timestamps=ts, **rk)
+    torch.cuda.synchronize()
+    g = [t.detach().cpu().numpy() for t in got[:3]]
+    same = [bool(np.array_equal(np.ascontiguousarray(a).view(np.uint32), np.ascontiguousarray(b.reshape(a.shape)).view(np.uint32)))
+            for a, b in zip(g, want[:3])]
+    return {"oracle_mode": mode, "rays": int(o.shape[0] * o.shape[1]), "pixel_stride": stride,
+            "samples_gpu": int(got[3]), "samples_oracle": int(want[3]), "samples_equal": int(got[3]) == int(want[3]),
+            "rgb_bitexact": same[0], "opacity_bitexact": same[1], "depth_bitexact": same[2], "bitexact": all(same),
+            "oracle_seconds": dt}
+
+
 def cpu_baseline_pytorch(sc, args):
     """The pure-PyTorch fp32 restatement (oracle/torch_oracle.py: torch field + compositing, native
     marching as in the reference) on the host cores, on a strided sample of the same frame."""
@@ -153,7 +189,8 @@ def cpu_baseline_pytorch(sc, args):
     t0 = time.perf_counter()
     out = TO.render_image_test(args.max_samples, tf, oest, o, d, timestamps=sc["timestamps"], **sc["render"])
     dt = time.perf_counter() - t0
-    return {"value": out[3] / dt, "unit": "samples/s", "cores": _t.get_num_threads(), "kind": "port (PyTorch fp32)",
+    return {"value": out[3] / dt, "unit": "samples/s", "cores": _t.get_num_threads(), "kind": "port",
+            "implementation": "PyTorch fp32 (oracle/torch_oracle.py: the pure-PyTorch path north_star names, torch ops on host cores)",
             "rays_per_sec": o.shape[0] * o.shape[1] / dt,
             "sample": f"every {s}th pixel in x and y of the same frame ({o.shape[0] * o.shape[1]} rays, {out[3]} samples, "
                       f"{dt:.1f} s)"}
@@ -175,10 +212,12 @@ def main():
     dev = torch.device("cuda", dev_index)
     import torch.distributed as dist
     if world > 1:
+        import datetime
+        pg_timeout = datetime.timedelta(seconds=max(10.0, args.comm_timeout))
         if backend == "nccl":
-            dist.init_process_group("nccl", device_id=dev)
+            dist.init_process_group("nccl", device_id=dev, timeout=pg_timeout)
         else:
-            dist.init_process_group(backend)
+            dist.init_process_group(backend, timeout=pg_timeout)
 
     from ced_nerf_amd import _lib, synthetic as S
     from ced_nerf_amd import dist as cdist
@@ -226,15 +265,12 @@ def main():
     rk = dict(sc["render"]); rk["render_bkgd"] = T(rk["render_bkgd"])
     ts = T(sc["timestamps"])
     from ced_nerf_amd import ops
-    # every lane's native calls run concurrently on their own threads and each holds one small all-reduce per
-    # iteration: one process group (communicator) per lane, created by all ranks in the same order
-    lane_groups = [dist.new_group(backend=backend) if world > 1 else None for _ in range(lanes)]
+    # Every call in flight needs one small all-reduce per iteration and one pixel all-gather per call.  All of them go
+    # through ONE process group (the default one) and are issued by ONE thread, the one that calls render_steps, in an
+    # order fixed by the lanes' own message sequences (dist.PipelinedRenderer): no rank can see another order.
     if world > 1:
-        # communicators are created lazily at a group's first collective (a rendezvous of all ranks): do it here, on the
-        # main thread, in the same order on every rank -- not later from the lanes' threads in whatever order they arrive
-        for g_ in lane_groups:
-            warm = torch.zeros(1, device=dev, dtype=torch.int64)
-            dist.all_reduce(warm, group=g_)
+        warm = torch.zeros(1, device=dev, dtype=torch.int64)
+        dist.all_reduce(warm)                   # the communicator is created here, by all ranks together
         torch.cuda.synchronize()
 
     def make_lanes(fc_):
@@ -242,8 +278,7 @@ def main():
         for l in range(lanes):
             fr = frames[l * fc_:(l + 1) * fc_]
             r_ = cdist.ShardedRenderer(field, est, world, rank, dev, max_samples=args.max_samples, render_kwargs=rk,
-                                       tile_order=os.environ.get("CED_TILE_ORDER", "1") != "0", units=per_call,
-                                       schedule_group=lane_groups[l])
+                                       tile_order=os.environ.get("CED_TILE_ORDER", "1") != "0", units=per_call)
             r_.set_rays(torch.stack([T(f["origins"]) for f in fr]), torch.stack([T(f["viewdirs"]) for f in fr]))
             out.append(r_)
         return out
@@ -259,7 +294,7 @@ def main():
         r.tracer = tracers[-1][0]
         lane_renderers.append(r)
     # multi-rank: the pixel all-gather of one step overlaps the next step's kernels (own stream, no read-back)
-    renderer = cdist.PipelinedRenderer(lane_renderers, async_gather=world > 1,
+    renderer = cdist.PipelinedRenderer(lane_renderers, async_gather=world > 1, comm_timeout_s=args.comm_timeout,
                                        field_max_blocks=int(os.environ.get("CED_FIELD_MAX_BLOCKS", "256")))
     field_ms, field_launches, field_samples = [0.0], [0], [0]
     step_no = [0]
@@ -402,13 +437,40 @@ def main():
                         "rays_per_sec": n_frames * args.width * args.height * k / float(tt2[0])}
     field.set_mlp_precision(args.mlp_precision)
     field._descriptor()
+    # the same step with the hash table stored in the OTHER type (fp16 <-> fp32), briefly: for hash_lookup_hbm_frac
+    other_table = None
+    if os.environ.get("CED_BENCH_OTHER_TABLE", "1") != "0":
+        p2 = dict(sc["params"]); h2 = dict(p2["hash"])
+        h2["table"] = np.ascontiguousarray(h2["table"].astype(np.float32 if h2["table"].dtype == np.float16 else np.float16))
+        p2["hash"] = h2
+        field2 = DNGPradianceField.from_params(p2, dev, mlp_precision=args.mlp_precision).eval()
+        field2._descriptor()
+        for r_ in lane_renderers:
+            r_.field = field2
+        step()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+        k = max(1, min(args.steps, 6))
+        t_a = time.perf_counter()
+        rows_o = renderer.render_steps(ts, k)
+        s_loc = sum(o["local_samples"] for row in rows_o for o in row)
+        del rows_o
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        d_o, s_o = reduce_window(time.perf_counter() - t_a, s_loc)
+        other_table = {"table": "f32" if h2["table"].dtype == np.float32 else "f16", "value": s_o / d_o, "unit": "samples/s", "steps": k}
+        for r_ in lane_renderers:
+            r_.field = field
+        del field2
     # several GPUs: the same steps in the OTHER scaling mode, briefly (same barrier / max-over-ranks discipline)
     other_scaling = None
     if world > 1:
         other = "weak" if args.scaling == "strong" else "strong"
         fc_o = frames_per_call_of(other)
         lanes_o = make_lanes(fc_o)
-        pipe_o = cdist.PipelinedRenderer(lanes_o, async_gather=True,
+        pipe_o = cdist.PipelinedRenderer(lanes_o, async_gather=True, comm_timeout_s=args.comm_timeout,
                                          field_max_blocks=int(os.environ.get("CED_FIELD_MAX_BLOCKS", "256")))
         pipe_o.render(ts)
         pipe_o.wait_gathers()
@@ -435,7 +497,7 @@ def main():
     single_ms, single_stats = None, None
     if not args.no_single_frame:
         alone = cdist.ShardedRenderer(field, est, world, rank, dev, max_samples=args.max_samples, render_kwargs=rk,
-                                      tile_order=os.environ.get("CED_TILE_ORDER", "1") != "0", schedule_group=lane_groups[0])
+                                      tile_order=os.environ.get("CED_TILE_ORDER", "1") != "0")
         alone.set_rays(torch.stack([T(f["origins"]) for f in frames[:1]]), torch.stack([T(f["viewdirs"]) for f in frames[:1]]))
         alone.tracer = tracers[0][0]
         alone.render_local(ts)                          # first call on this stream allocates its workspace
@@ -461,8 +523,13 @@ def main():
     comm_info = None
     if world > 1:
         comm_info = {"backend": dist.get_backend(), "ranks": dist.get_world_size(),
-                     "schedule_exchange": "per iteration and call one all-reduce(sum) of [frames_per_call] int64 on the "
-                                          "call's stream, one process group per call in flight",
+                     "design": "one communicator, one issuing thread per rank: a lane's native call hands every iteration's "
+                               "survivor-count row ([frames_per_call] int64) to the thread that called render_steps, which "
+                               "takes one message per lane in turn (round robin) and enqueues the all-reduce on that lane's "
+                               "stream, and the pixel all-gather when the lane reports its call finished; the order depends "
+                               "on the lanes' message sequences only, which the image-global schedule makes identical on "
+                               "every rank",
+                     "timeout_s": args.comm_timeout,
                      "schedule_allreduces_last_call": int(getattr(lane_renderers[0].exchange, "calls", 0))}
     if rank != 0:
         if world > 1:
@@ -583,7 +650,7 @@ def main():
                   "avg_launch_ms_raw": raw_dev_ms if raw_dev_ms is not None else raw_avg_ms,
                   "timing": "device stamps" if avg_ms is not avg_events_ms else "hip events",
                   "hip_events": {"avg_launch_ms": avg_events_ms, "avg_launch_ms_raw": raw_avg_ms,
-                                 "frac": (samples_per_launch * ((ALG_FLOPS_SIGMA_CHAIN / PEAK_F32_MFMA_TFLOPS + 3.0 * ALG_FLOPS_HEAD / PEAK_F16_MFMA_TFLOPS) / 1e12
+                                 "frac": (samples_per_launch * ((ALG_FLOPS_SIGMA_CHAIN / PEAK_F32_MFMA_TFLOPS + ALG_FLOPS_HEAD / PEAK_F16_MFMA_TFLOPS) / 1e12
                                                                 if args.mlp_precision == "f32+h16x2" else
                                                                 ALG_FLOPS_PER_SAMPLE / 1e12 / PEAK_F32_MFMA_TFLOPS if args.mlp_precision == "f32"
                                                                 else (ALG_BYTES_PER_SAMPLE_F16 if fp16 else ALG_BYTES_PER_SAMPLE_F32) / 1e9 / PEAK_HBM_GBS)
@@ -606,7 +673,7 @@ def main():
             s_ms = single_field["ms"] / single_field["launches"]
             s_spl = single_field["units"] / single_field["launches"]
             s_tf = s_spl * (ALG_FLOPS_SIGMA_CHAIN if mixed else ALG_FLOPS_PER_SAMPLE) / (s_ms * 1e-3) / 1e12
-            s_tf16 = s_spl * 3.0 * ALG_FLOPS_HEAD / (s_ms * 1e-3) / 1e12 if mixed else 0.0
+            s_tf16 = s_spl * ALG_FLOPS_HEAD / (s_ms * 1e-3) / 1e12 if mixed else 0.0
             s_gbs = s_spl * alg_bytes / (s_ms * 1e-3) / 1e9
             line["roofline_single_frame"] = (
                 {"bound": "mfma", "achieved": s_tf, "peak": mfma_peak, "unit": "TFLOP/s",
@@ -618,7 +685,7 @@ def main():
             # MFMA (2.5 PF dense; three fp16 product blocks per algorithmic one).  `frac` = the share of the launch
             # time the two matrix pipes need at their peaks -- f16 FLOPs are never priced at the fp32 peak.
             tf32 = samples_per_launch * ALG_FLOPS_SIGMA_CHAIN / (avg_ms * 1e-3) / 1e12
-            tf16 = samples_per_launch * 3.0 * ALG_FLOPS_HEAD / (avg_ms * 1e-3) / 1e12
+            tf16 = samples_per_launch * ALG_FLOPS_HEAD / (avg_ms * 1e-3) / 1e12         # ALGORITHMIC flops (the split issues 3x)
             r_mfma.update({"achieved": tf32, "peak": PEAK_F32_MFMA_TFLOPS, "frac": tf32 / PEAK_F32_MFMA_TFLOPS + tf16 / PEAK_F16_MFMA_TFLOPS,
                            "alg_flops_per_sample": ALG_FLOPS_SIGMA_CHAIN,
                            "mfma_classes": {
@@ -626,19 +693,36 @@ def main():
                                        "unit": "TFLOP/s", "frac": tf32 / PEAK_F32_MFMA_TFLOPS},
                                "f16": {"alg_flops_per_sample": ALG_FLOPS_HEAD, "issued_flops_per_sample": 3.0 * ALG_FLOPS_HEAD,
                                        "achieved": tf16, "peak": PEAK_F16_MFMA_TFLOPS, "unit": "TFLOP/s",
-                                       "frac": tf16 / PEAK_F16_MFMA_TFLOPS}},
+                                       "frac": tf16 / PEAK_F16_MFMA_TFLOPS,
+                                       "note": "achieved / frac count the ALGORITHMIC flops; the split form issues three times as many"}},
                            "hash_lookup_hbm_frac": samples_per_launch * 1024.0 / (avg_ms * 1e-3) / 1e9 / PEAK_HBM_GBS})
+        # SURVEY 8d's primary figure: the hash lookup alone (L * 8 corners * F features * sizeof(feature) = 1024 B per sample
+        # from an fp32 table, 512 B from an fp16 one) against HBM peak, for BOTH table types: this run's table from the
+        # field kernel's executing time, the other table type from a short run of the same pipeline (`other_table`)
+        hl_b = 512.0 if fp16 else 1024.0
+        hash_lookup = {("f16_table_512B" if fp16 else "f32_table_1024B"): {
+            "bytes_per_sample": hl_b, "frac_kernel_time": samples_per_launch * hl_b / (avg_ms * 1e-3) / 1e9 / PEAK_HBM_GBS,
+            "frac_whole_pipeline": samples_total / dt * hl_b / 1e9 / PEAK_HBM_GBS / world}}
+        if other_table is not None:
+            ob = 1024.0 if fp16 else 512.0
+            hash_lookup["f32_table_1024B" if fp16 else "f16_table_512B"] = {
+                "bytes_per_sample": ob, "samples_per_sec": other_table["value"],
+                "frac_whole_pipeline": other_table["value"] * ob / 1e9 / PEAK_HBM_GBS / world,
+                "note": "short run (%d steps) of the same pipeline with the table stored in the other type: the bytes halve "
+                        "or double, the time does not (the gathers are served from L2 / Infinity Cache)" % other_table["steps"]}
+        r_hbm["hash_lookup_hbm_frac"] = hash_lookup
+        r_mfma["hash_lookup_hbm_frac"] = hash_lookup
         line["roofline"] = dict(r_mfma if exact else r_hbm, **common)
         line["roofline_hbm" if exact else "roofline_mfma"] = r_hbm if exact else r_mfma
         line["kernel_ms_per_step"] = {k: v["ms"] / min(args.steps, 24) for k, v in prof.items()}
     if others:
-        notes = {"f32+h16x2": "sigma chain exact (counts / opacity / depth bit-identical to the oracle), colour head on split-fp16 "
-                              "MFMA: rgb <= 1e-4",
-                 "f16x2": "split-fp16 MFMA MLPs, fp32 accumulate: pixels within 1e-4 of the oracle, sample count within 1e-5 "
-                          "relative (early-stop decisions at rounding distance from the threshold may flip)",
-                 "f16": "fp16-operand MLPs (the reference's tcnn class; BASELINE config 5 with --table-dtype f16): parity "
-                        "against the oracle's fp16-operand mode, tolerance in tests/test_gpu_parity.py",
-                 "f32": "exact fp32 MFMA chain: bit-identical to the oracle"}
+        notes = {"f32+h16x2": "sigma chain on exact fp32 MFMA (counts / opacity / depth bit-identical to the PLAIN oracle), colour "
+                              "head on split-fp16 MFMA: rgb <= 1e-4, and bit-identical to the oracle's f32+h16x2 mode",
+                 "f16x2": "split-fp16 MFMA MLPs, fp32 accumulate: bit-identical to the oracle's f16x2 mode; within 1e-4 of the "
+                          "plain fp32 oracle",
+                 "f16": "fp16-operand MLPs (the reference's tcnn class; BASELINE config 5 with --table-dtype f16): "
+                        "bit-identical to the oracle's f16 mode (tests/test_gpu_fullframe.py C5)",
+                 "f32": "exact fp32 MFMA chain: bit-identical to the plain oracle"}
         for k_, v_ in others.items():
             v_["parity"] = notes[k_]
         line["other_mlp_precisions"] = others
@@ -692,6 +776,31 @@ def main():
                 timed0 = (o0["rgb"][0], o0["opacity"][0], o0["depth"][0])
             torch.cuda.synchronize()
             line["parity_vs_oracle"] = parity_vs_oracle(oracle_out, single, timed0, args.mlp_precision)
+            line["parity_vs_oracle"]["oracle"] = "plain fp32 (the reference arithmetic); north-star: counts equal, pixels <= 1e-4"
+            # every TIMED frame, not only frame 0: its sample total in the timed mode against the total of the exact fp32
+            # mode (itself bit-identical to the plain oracle: tests/test_gpu_fullframe.py), and the timed pipeline's per-call
+            # totals against the sums of its frames rendered alone
+            if args.mlp_precision != "f32":
+                tot_mode, tot_exact = [], []
+                for fr in frames[:n_frames]:
+                    rr = Rays(T(fr["origins"]), T(fr["viewdirs"]))
+                    field.set_mlp_precision(args.mlp_precision)
+                    tot_mode.append(int(render_image_test(args.max_samples, field, est, rr, timestamps=ts, **rk)[3]))
+                    field.set_mlp_precision("f32")
+                    tot_exact.append(int(render_image_test(args.max_samples, field, est, rr, timestamps=ts, **rk)[3]))
+                field.set_mlp_precision(args.mlp_precision)
+                calls_ok = None
+                if last_row is not None:
+                    calls_ok = all(int(o_["total_samples"]) == sum(tot_mode[l * fpc_main:(l + 1) * fpc_main])
+                                   for l, o_ in enumerate(last_row))
+                line["parity_vs_oracle"]["timed_frames"] = {
+                    "frames": len(tot_mode), "samples_equal_frames": int(sum(a == b for a, b in zip(tot_mode, tot_exact))),
+                    "samples_equal": tot_mode == tot_exact, "max_abs_difference": int(max(abs(a - b) for a, b in zip(tot_mode, tot_exact))),
+                    "timed_calls_equal_sum_of_single_renders": calls_ok,
+                    "against": "the exact fp32 mode's per-frame totals (GPU), which the tests tie bit for bit to the plain oracle"}
+            if args.mlp_precision != "f32" and args.oracle_mode_stride > 0:
+                line["parity_vs_oracle_mode"] = parity_vs_oracle_mode(sc, args, field, est, rk, ts, T, args.mlp_precision,
+                                                                      args.oracle_mode_stride)
             # the other arithmetic modes of `other_mlp_precisions`, same frame, same (fp32) oracle pixels: PSNR / max error
             for prec in [p for p in args.also.split(",") if p and p != args.mlp_precision]:
                 field.set_mlp_precision(prec)
@@ -709,4 +818,14 @@ def main():
 
 
 if __name__ == "__main__":
-    main()
+    try:
+        main()
+    except Exception as e:      # noqa: BLE001
+        from ced_nerf_amd.dist import ExchangeTimeout
+        if not isinstance(e, ExchangeTimeout):
+            raise
+        # a stuck exchange: say where, and leave with a status -- lanes may still sit in native calls, so no clean-up, no
+        # interpreter shutdown that would join them, and never a re-exec of a process that has touched the GPU
+        sys.stderr.write(f"bench.py: rank {os.environ.get('RANK', '0')}: {e}\n")
+        sys.stderr.flush()
+        os._exit(3)

@@ -86,6 +86,7 @@ class ShardedRenderer:
         # issued in the same order on every rank, and the lanes' threads issue theirs independently
         self.schedule_group = schedule_group
         self.exchange = None           # ops.ScheduleExchange of the current image shape
+        self.exchange_issuer = None    # PipelinedRenderer: who issues this renderer's collectives (ops.ScheduleExchange.issuer)
         self.sharded = False
 
     def _hip_render(self, rays_o, rays_d, timestamps):
@@ -100,6 +101,7 @@ class ShardedRenderer:
                 self.exchange = ops.ScheduleExchange(F, H * W, self.local_real, rays_o.device, self.max_samples,
                                                      float(self.render_kwargs.get("cone_angle", 0.0)),
                                                      group=self.schedule_group)
+            self.exchange.issuer = self.exchange_issuer
             rgb, op, dp, totals = render_frames_test(
                 self.max_samples, self.field, self.estimator, Rays(rays_o.view(F, -1, 3), rays_d.view(F, -1, 3)), timestamps=ts,
                 tracer=self.tracer, field_max_workgroups=self.field_max_workgroups, exchange=self.exchange,
@@ -209,13 +211,13 @@ class ShardedRenderer:
         payload[-1, 0] = float(n_samples >> 16)          # exact in float32: two 16-bit halves
         payload[-1, 1] = float(n_samples & 0xFFFF)
         gathered = torch.empty((self.world, self.n_pad + 1, 5), device=rgb.device, dtype=torch.float32)
-        if payload.is_cuda and dist.get_backend() == "gloo":
+        if payload.is_cuda and dist.get_backend(self.schedule_group) == "gloo":
             # rehearsal of the multi-rank path without RCCL (ranks sharing one card): stage through the host
             parts = [torch.empty((self.n_pad + 1, 5), dtype=torch.float32) for _ in range(self.world)]
-            dist.all_gather(parts, payload.cpu())
+            dist.all_gather(parts, payload.cpu(), group=self.schedule_group)
             gathered.copy_(torch.stack(parts))
         else:
-            dist.all_gather_into_tensor(gathered.view(-1, 5), payload)
+            dist.all_gather_into_tensor(gathered.view(-1, 5), payload, group=self.schedule_group)
         tail = gathered[:, -1, :2].to(torch.float64)
         total_t = (tail[:, 0] * 65536.0 + tail[:, 1]).sum()
         total = int(total_t.item()) if sync_total else None
@@ -236,6 +238,20 @@ class ShardedRenderer:
         return self.gather(self.render_local(timestamps))
 
 
+def _all_reduce_on(row: torch.Tensor, stream: int, group) -> None:
+    """all-reduce(sum) of `row`, enqueued on the HIP stream with handle `stream` (0: the current one; host tensors: now)"""
+    if not row.is_cuda:
+        dist.all_reduce(row, op=dist.ReduceOp.SUM, group=group)
+        return
+    ext = torch.cuda.ExternalStream(stream, device=row.device) if stream else torch.cuda.current_stream(row.device)
+    with torch.cuda.stream(ext):
+        dist.all_reduce(row, op=dist.ReduceOp.SUM, group=group)
+
+
+class ExchangeTimeout(RuntimeError):
+    """A lane or the collecting thread of a PipelinedRenderer waited longer than `comm_timeout_s` for its counterpart."""
+
+
 class PipelinedRenderer:
     """Several independent ray batches ("lanes", e.g. consecutive frames of a video) in flight at once.
 
@@ -243,12 +259,27 @@ class PipelinedRenderer:
     marching / compositing launches and the per-iteration host round trip of one frame overlap the
     MFMA-bound field kernel of another (frames are independent: train_real.py:531-558 renders them
     one after the other).  Every lane is a complete render_image_test call, so per-frame results
-    are exactly those of rendering the frames one at a time.  Collectives are issued afterwards by
-    the calling thread, lane by lane, i.e. in the same order on every rank.
+    are exactly those of rendering the frames one at a time.
+
+    Collectives (several ranks): ONE issuing thread, ONE communicator, an order no rank can disagree on.  A lane never
+    calls torch.distributed itself.  Its native call asks for the all-reduce of an iteration's survivor counts through
+    `ops.ScheduleExchange.issuer`: the request goes into the lane's message queue and the lane's thread waits until the
+    collecting thread (the caller of `render` / `render_steps`) has enqueued the collective on the lane's stream; a
+    finished call is a message too, answered with the pixel all-gather.  The collecting thread takes ONE message from
+    each lane in turn, round robin, skipping only lanes that have delivered all their steps.  A lane's message sequence
+    (the iterations of its calls and their ends) is fixed by the image-global schedule, identical on every rank, so the
+    order in which collectives reach the communicator is identical on every rank whatever the lanes' relative speed --
+    which is all RCCL asks for; there is nothing for two ranks to wait for each other on.  (Rounds 2-3 gave every lane a
+    communicator of its own and let the lanes' threads issue; that is deadlock-free only if every communicator's stream
+    progresses independently of the others, a property of hardware-queue placement that could not be verified.)
+    All lanes must use the same process group (ShardedRenderer.schedule_group); a mixture raises.  Every wait of this
+    protocol has a deadline (`comm_timeout_s`, default $CED_COMM_TIMEOUT_S or 120): on expiry ExchangeTimeout names
+    the lane, step and iteration that is stuck; a collective stuck ON THE DEVICE is the process group's own timeout
+    (torch.distributed.init_process_group(timeout=...), which bench.py sets to the same figure).
 
     Streams: every lane has its own stream (plus one for the gathers).  HIP maps a process's streams onto 4 hardware
     queues by default and streams sharing a queue serialise: with more than 3 lanes, or 3 lanes and async_gather, export
-    GPU_MAX_HW_QUEUES=8 before the process initialises HIP (bench.py does).
+    GPU_MAX_HW_QUEUES=8 before the process initialises HIP (bench.py does).  That is a matter of speed only.
 
     async_gather=True (multi-rank video rendering): the gathers and the un-permute run on a communication
     stream of their own and `render` returns without waiting for them, so the exchange of one step overlaps
@@ -256,7 +287,8 @@ class PipelinedRenderer:
     device synchronise), and the all-rank sample count stays on the device (`total_samples_tensor`)."""
 
     def __init__(self, lanes, share_field_stream: bool = False, async_gather: bool = False,
-                 field_max_blocks: Optional[int] = 128):
+                 field_max_blocks: Optional[int] = 128, comm_timeout_s: Optional[float] = None):
+        import os
         from concurrent.futures import ThreadPoolExecutor
         self.lanes = list(lanes)
         # With several frames in flight a field launch is capped at half the CUs (a per-call property of the lanes'
@@ -268,10 +300,24 @@ class PipelinedRenderer:
             for lane in self.lanes:
                 lane.field_max_workgroups = int(self.field_max_blocks)
         self.async_gather = bool(async_gather)
+        self.comm_timeout_s = float(comm_timeout_s if comm_timeout_s is not None else os.environ.get("CED_COMM_TIMEOUT_S", "120"))
         self.comm_stream = None
         self.streams = [torch.cuda.Stream(device=l.device) if torch.cuda.is_available() and str(l.device) != "cpu"
                         else None for l in self.lanes]
         self.pool = ThreadPoolExecutor(max_workers=len(self.lanes)) if len(self.lanes) > 1 else None
+        collective = [l for l in self.lanes if getattr(l, "world", 1) > 1 or getattr(l, "force_collective", False)]
+        if self.pool is not None and collective:
+            groups = {id(getattr(l, "schedule_group", None)) for l in self.lanes}
+            if len(groups) != 1:
+                raise ValueError("PipelinedRenderer: the lanes use different process groups; every lane's collectives are "
+                                 "issued by ONE thread on ONE communicator (pass the same schedule_group, or None, to all)")
+            for i, lane in enumerate(self.lanes):
+                lane.exchange_issuer = self._issuer_of_lane(i)
+                if getattr(lane, "exchange", None) is not None:
+                    lane.exchange.issuer = lane.exchange_issuer
+        self._msgq = None              # per-lane message queues of the running render_steps
+        self._abort = None             # the exception that ended it, seen by lanes waiting for an acknowledgement
+        self._where = None             # (lane, step) the collecting thread is waiting for: diagnostics
         if share_field_stream and self.pool is not None and self.streams[0] is not None:
             # Optional: one stream for every lane's field kernel, so those launches queue instead of
             # sharing the chip (clean per-launch timings).  Off by default: letting the field kernels of
@@ -279,6 +325,29 @@ class PipelinedRenderer:
             self.field_stream = torch.cuda.Stream(device=self.lanes[0].device)
             for lane in self.lanes:
                 lane.field_stream = self.field_stream
+
+    def _issuer_of_lane(self, i):
+        """ops.ScheduleExchange.issuer of lane i: runs on the lane's thread inside its native call."""
+        import threading
+
+        def issue(exchange, row, stream, iteration):
+            q = self._msgq
+            if q is None:                  # the lane renders outside render / render_steps (lane.render_local): on its own
+                _all_reduce_on(row, stream, exchange.group)
+                return
+            ack, box = threading.Event(), {}
+            q[i].put(("reduce", iteration, row, stream, exchange.group, ack, box))
+            waited = 0.0
+            while not ack.wait(0.05):
+                waited += 0.05
+                if self._abort is not None:
+                    raise self._abort
+                if waited >= self.comm_timeout_s:
+                    raise ExchangeTimeout(f"lane {i}: the survivor-count all-reduce of iteration {iteration} was not issued within "
+                                          f"{self.comm_timeout_s:.0f} s; the collecting thread is waiting for (lane, step) {self._where}")
+            if "error" in box:
+                raise box["error"]
+        return issue
 
     def _lane(self, i, timestamps):
         lane, stream = self.lanes[i], self.streams[i]
@@ -289,39 +358,16 @@ class PipelinedRenderer:
 
     @torch.no_grad()
     def render(self, timestamps: torch.Tensor):
-        if self.pool is None:
-            locals_ = [self._lane(0, timestamps)]
-        else:
-            main = torch.cuda.current_stream() if self.streams[0] is not None else None
-            if main is not None:
-                for s in self.streams:
-                    s.wait_stream(main)             # the inputs were produced on the caller's stream
-            futures = [self.pool.submit(self._lane, i, timestamps) for i in range(len(self.lanes))]
-            locals_ = [f.result() for f in futures]
-            if main is not None and not self.async_gather:
-                for s, loc in zip(self.streams, locals_):
-                    main.wait_stream(s)
-                    for t in loc[:3]:
-                        t.record_stream(main)           # produced on the lane's stream, consumed on the caller's
-        if not self.async_gather or self.streams[0] is None:
-            return [lane.gather(loc) for lane, loc in zip(self.lanes, locals_)]
-        if self.comm_stream is None:
-            self.comm_stream = torch.cuda.Stream(device=self.lanes[0].device)
-        outs = []
-        with torch.cuda.stream(self.comm_stream):
-            for lane, loc, s in zip(self.lanes, locals_, self.streams):
-                self.comm_stream.wait_stream(s)
-                for t in loc[:3]:
-                    t.record_stream(self.comm_stream)       # produced on the lane's stream, consumed here
-                outs.append(lane.gather(loc, sync_total=False))
-        return outs
+        """One step: one call per lane, gathered.  (`render_steps` with a single step.)"""
+        return self.render_steps(timestamps, 1)[0]
 
     @torch.no_grad()
     def render_steps(self, timestamps: torch.Tensor, n_steps: int, before_frame: Optional[Callable] = None):
-        """`n_steps` consecutive steps (each step = one frame per lane, as `render`) WITHOUT joining the lanes between
+        """`n_steps` consecutive steps (each step = one frame per lane) WITHOUT joining the lanes between
         steps: every lane renders its frame n_steps times back to back, so a lane that finishes early starts its next
-        frame instead of waiting for the slowest one (a video is a stream of frames).  Gathers are issued by the
-        calling thread in (step, lane) order -- the same order on every rank -- as the frames complete.
+        frame instead of waiting for the slowest one (a video is a stream of frames).  The calling thread collects the
+        lanes' messages -- requests for an iteration's all-reduce, finished calls -- one per lane in turn and issues every
+        collective itself (class comment).
         `before_frame(lane_index, step)` runs on the lane's thread (with the lane's stream current) before each frame,
         e.g. to swap tracers or to hand the lane the rays of its next frame.  `timestamps` may be a callable
         `(lane_index, step) -> tensor` for per-frame times.  An exception on a lane's thread is re-raised here.
@@ -331,8 +377,9 @@ class PipelinedRenderer:
         main = torch.cuda.current_stream() if self.streams[0] is not None else None
         if main is not None:
             for s in self.streams:
-                s.wait_stream(main)
-        done = [[queue.Queue(maxsize=1) for _ in range(L)] for _ in range(n_steps)]
+                s.wait_stream(main)             # the inputs were produced on the caller's stream
+        msgq = [queue.Queue() for _ in range(L)]
+        self._msgq, self._abort = msgq, None
 
         def work(i):
             step = 0
@@ -352,43 +399,85 @@ class PipelinedRenderer:
                             ts = timestamps(i, step)
                     else:
                         ts = timestamps(i, step) if callable(timestamps) else timestamps
-                    done[step][i].put(self._lane(i, ts))
+                    msgq[i].put(("done", step, self._lane(i, ts)))
             except BaseException as e:           # hand the failure to the collecting thread instead of leaving it waiting
-                for s in range(step, n_steps):
-                    if done[s][i].empty():
-                        done[s][i].put(e)
+                msgq[i].put(("error", step, e))
 
-        if self.pool is None:
-            work(0)
-            threads = []
-        else:
-            threads = [self.pool.submit(work, i) for i in range(L)]
         if self.async_gather and self.streams[0] is not None and self.comm_stream is None:
             self.comm_stream = torch.cuda.Stream(device=self.lanes[0].device)
-        outs = []
-        for step in range(n_steps):
-            row = []
-            for i, lane in enumerate(self.lanes):
-                loc = done[step][i].get()
-                if isinstance(loc, BaseException):
-                    for t in threads:
-                        t.result()
-                    raise loc
-                if self.async_gather and self.streams[0] is not None:
-                    with torch.cuda.stream(self.comm_stream):
-                        self.comm_stream.wait_stream(self.streams[i])
-                        for t in loc[:3]:
-                            t.record_stream(self.comm_stream)
-                        row.append(lane.gather(loc, sync_total=False))
+
+        def gather(i, loc):
+            lane = self.lanes[i]
+            if self.async_gather and self.streams[0] is not None:
+                with torch.cuda.stream(self.comm_stream):
+                    self.comm_stream.wait_stream(self.streams[i])
+                    for t in loc[:3]:
+                        t.record_stream(self.comm_stream)       # produced on the lane's stream, consumed here
+                    return lane.gather(loc, sync_total=False)
+            if main is not None:
+                main.wait_stream(self.streams[i])
+                for t in loc[:3]:
+                    t.record_stream(main)
+            return lane.gather(loc)
+
+        outs = [[None] * L for _ in range(n_steps)]
+        if self.pool is None:
+            # one lane: it runs on this thread; without an issuer its exchange issues its own collectives, in program order
+            work(0)
+            for step in range(n_steps):
+                kind, st, payload = msgq[0].get()
+                if kind == "error":
+                    self._msgq = None
+                    raise payload
+                outs[st][0] = gather(0, payload)
+            self._msgq = None
+            return outs
+        threads = [self.pool.submit(work, i) for i in range(L)]
+        step_of = [0] * L
+        failure = None
+        lane_i = 0
+        try:
+            while any(s < n_steps for s in step_of):
+                if step_of[lane_i] >= n_steps:
+                    lane_i = (lane_i + 1) % L
+                    continue
+                self._where = (lane_i, step_of[lane_i])
+                try:
+                    msg = msgq[lane_i].get(timeout=self.comm_timeout_s)
+                except queue.Empty:
+                    raise ExchangeTimeout(f"lane {lane_i}, step {step_of[lane_i]}: no message (all-reduce request or finished "
+                                          f"call) for {self.comm_timeout_s:.0f} s; steps delivered per lane: {step_of}") from None
+                if msg[0] == "reduce":
+                    _, iteration, row, stream, group, ack, box = msg
+                    try:
+                        _all_reduce_on(row, stream, group)
+                    except BaseException as e:
+                        box["error"] = e
+                        ack.set()
+                        raise
+                    ack.set()
+                elif msg[0] == "done":
+                    outs[msg[1]][lane_i] = gather(lane_i, msg[2])
+                    step_of[lane_i] += 1
                 else:
-                    if main is not None:
-                        main.wait_stream(self.streams[i])
-                        for t in loc[:3]:
-                            t.record_stream(main)
-                    row.append(lane.gather(loc))
-            outs.append(row)
-        for t in threads:
-            t.result()
+                    raise msg[2]
+                lane_i = (lane_i + 1) % L
+        except BaseException as e:
+            failure = e
+            self._abort = e                       # lanes waiting for an acknowledgement give up with the same error
+        finally:
+            if failure is not None and not isinstance(failure, ExchangeTimeout):
+                for t in threads:                 # the lanes end by themselves (their waits see _abort); a timeout does not wait
+                    try:
+                        t.result(timeout=self.comm_timeout_s)
+                    except BaseException:
+                        pass
+            elif failure is None:
+                for t in threads:
+                    t.result()
+            self._msgq = None
+        if failure is not None:
+            raise failure
         return outs
 
     def wait_gathers(self) -> None:

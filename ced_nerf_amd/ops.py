@@ -877,8 +877,11 @@ class ScheduleExchange:
     the image-global N_alive of cednerf/utils.py:231-235.
 
     One instance per concurrently running native call (a lane of PipelinedRenderer): the per-iteration rows live in a
-    buffer of its own, and with several lanes every lane needs ITS OWN process group -- the lanes' threads issue their
-    collectives independently, and collectives of one communicator must be issued in the same order on every rank.
+    buffer of its own.  Collectives of one communicator must be issued in the same order on every rank, and the lanes'
+    threads run independently -- so with several lanes NO lane issues its own collective: `issuer` (set by
+    PipelinedRenderer) hands the row to the ONE collecting thread, which issues every lane's all-reduces and pixel gathers
+    on ONE process group in an order that depends on the lanes' own message sequences only, never on timing
+    (dist.PipelinedRenderer.render_steps).  Without an issuer (a renderer on its own) the all-reduce is issued here.
 
     global_rays: rays of the whole image; local_rays [n_frames]: the real (unpadded) rays of this rank's share of every
     frame.  `reduce_fn(tensor)` replaces the all-reduce (tests)."""
@@ -895,11 +898,16 @@ class ScheduleExchange:
         assert self.local_rays.numel() == self.n_frames
         self.group, self.error, self.calls = group, None, 0
         self._reduce_fn = reduce_fn
+        self.issuer = None             # callable(exchange, row, stream_handle, iteration): see the class comment
 
         def _cb(user, counts_ptr, n_counts, iteration, stream):
             try:
                 row = self.counts[iteration]
                 assert row.data_ptr() == counts_ptr and n_counts == self.n_frames
+                if self.issuer is not None and self._reduce_fn is None:
+                    self.issuer(self, row, stream or 0, iteration)     # returns once the collective is enqueued on `stream`
+                    self.calls += 1
+                    return 0
                 cur = torch.cuda.current_stream(row.device)
                 if cur.cuda_stream != (stream or 0):           # not the thread's current stream: make it so
                     cur = torch.cuda.ExternalStream(stream, device=row.device)

@@ -181,3 +181,87 @@ def test_sharded_render_world2_gloo_matches_single_process(tmp_path):
     assert int(r0["total"]) == int(r1["total"]) == want["total_samples"] == int(r0["local"]) + int(r1["local"])
     assert int(r0["n_local"]) + int(r1["n_local"]) == 2 * 40 * 24
     assert want["rgb"].shape == (2, 24, 40, 3) and want["rgb"].std() > 0.01
+
+
+# ---- several lanes, several ranks: ONE collecting thread issues every collective in an order timing cannot change ----
+def _lane_script(lane, step):
+    """how many all-reduce requests the call (lane, step) makes: differs per lane and step, identical on every rank"""
+    return 2 + (3 * lane + 5 * step) % 4
+
+
+def _worker_funnel(rank, world, port, out_dir, stall_lane):
+    import time
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    torch.set_num_threads(1)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from ced_nerf_amd.dist import ExchangeTimeout, PipelinedRenderer, ShardedRenderer
+
+    class Ex:                                  # what the issuer needs of an ops.ScheduleExchange
+        group = None
+
+    H, W, L, n_steps = 16, 16, 3, 4
+    rng = np.random.default_rng(100 + rank)    # rank-DEPENDENT delays: the lanes interleave differently on the two ranks
+    log = []
+    lanes = []
+    for l in range(L):
+        r = ShardedRenderer(None, None, world, rank, "cpu")
+        state = {"step": 0}
+
+        def fn(o, d, ts, r=r, l=l, state=state):
+            step = state["step"]; state["step"] += 1
+            for it in range(_lane_script(l, step)):
+                time.sleep(float(rng.uniform(0, 0.02)))
+                if stall_lane == l and rank == 1 and step == 1 and it == 1:
+                    time.sleep(3.0)            # one rank's lane goes silent: the other rank must time out, not hang
+                row = torch.tensor([rank + 1, 10 * l + step, it], dtype=torch.int64)
+                r.exchange_issuer(Ex, row, 0, it)
+                assert row.tolist() == [3, 2 * (10 * l + step), 2 * it], (l, step, it, row.tolist())
+                log.append((l, step, it))
+            n = o.shape[0]
+            val = float(100 * l + step)
+            return torch.full((n, 3), val), torch.full((n, 1), val), torch.full((n, 1), float(rank)), 7
+        r.render_fn = fn
+        r.set_rays(torch.zeros(1, H, W, 3), torch.ones(1, H, W, 3))
+        lanes.append(r)
+    pipe = PipelinedRenderer(lanes, comm_timeout_s=1.0 if stall_lane >= 0 else 30.0)
+    try:
+        outs = pipe.render_steps(torch.zeros(1), n_steps)
+        ok = all(float(outs[s][l]["rgb"].min()) == float(outs[s][l]["rgb"].max()) == 100 * l + s and outs[s][l]["total_samples"] == 14
+                 for s in range(n_steps) for l in range(L))
+        res = "ok" if ok and len(log) == sum(_lane_script(l, s) for l in range(L) for s in range(n_steps)) else "wrong"
+    except ExchangeTimeout as e:
+        res = "timeout: " + str(e)
+    except BaseException as e:                 # e.g. gloo: "connection closed by peer" once the other rank has left
+        res = "error: " + str(e)
+    open(os.path.join(out_dir, f"rank{rank}.txt"), "w").write(res)
+    if res != "ok":
+        os._exit(0)          # as bench.py does: lanes may still sit in a wait; never hang the process on them
+    dist.destroy_process_group()
+
+
+def test_lanes_of_two_ranks_funnel_their_collectives_through_one_thread(tmp_path):
+    """3 lanes x 4 steps on 2 gloo ranks; every call asks for 2-5 all-reduces after random, rank-dependent delays.  Every
+    reduced row must be the sum of the SAME (lane, step, iteration) row of both ranks -- any disagreement about the order
+    of the collectives on the shared communicator would add up different rows (or hang) -- and every gathered image is
+    its (lane, step)'s own."""
+    mp.spawn(_worker_funnel, args=(2, _free_port(), str(tmp_path), -1), nprocs=2, join=True)
+    assert [open(os.path.join(tmp_path, f"rank{r}.txt")).read() for r in range(2)] == ["ok", "ok"]
+
+
+def test_a_stuck_lane_ends_in_a_named_timeout_not_in_a_hang(tmp_path):
+    """Rank 1's lane 2 goes silent for 3 s with a 1 s deadline: rank 1 names the (lane, step) it was waiting for and
+    leaves; rank 0 (whose collecting thread sits in gloo's blocking all-reduce of that very iteration) ends with a timeout
+    of its other lanes or with gloo's "peer gone".  Nobody waits for ever, nobody reports success."""
+    mp.spawn(_worker_funnel, args=(2, _free_port(), str(tmp_path), 2), nprocs=2, join=True)
+    msgs = [open(os.path.join(tmp_path, f"rank{r}.txt")).read() for r in range(2)]
+    assert all(m.startswith("timeout: ") or m.startswith("error: ") for m in msgs), msgs
+    assert msgs[1].startswith("timeout: ") and "lane 2, step 1" in msgs[1], msgs
+
+
+def test_lanes_on_different_process_groups_are_refused():
+    from ced_nerf_amd.dist import PipelinedRenderer, ShardedRenderer
+    a = ShardedRenderer(None, None, 2, 0, "cpu", schedule_group=object())
+    b = ShardedRenderer(None, None, 2, 0, "cpu", schedule_group=object())
+    with pytest.raises(ValueError, match="ONE communicator"):
+        PipelinedRenderer([a, b])
+    PipelinedRenderer([ShardedRenderer(None, None, 1, 0, "cpu"), ShardedRenderer(None, None, 1, 0, "cpu")])   # no collectives: fine

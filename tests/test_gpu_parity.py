@@ -1747,10 +1747,12 @@ def test_bench_two_rank_rehearsal():
     exchange, frames in flight, the asynchronous pixel gather, the other precision modes, rank 0's JSON line with BOTH
     scalings.  The ranks share this box's one card, so the collectives run over gloo (CED_BENCH_BACKEND=gloo); with
     RCCL only the backend differs."""
-    d = _two_rank_bench(["--also", "f16x2"])
-    assert d["n_gpus"] == 2 and d["steps"] == 2 and d["scaling"] == "strong" and d["value"] > 0
-    assert d["config"]["frames_per_step"] == 9 and d["config"]["frames_per_call"] == 3 and "f16x2" in d["other_mlp_precisions"]
-    assert d["roofline"]["bound"] == "mfma" and 0 < d["roofline"]["frac"] < 1
+    d = _two_rank_bench(["--also", "f32+h16x2"])
+    assert d["n_gpus"] == 2 and d["steps"] == 2 and d["scaling"] == "strong" and d["value"] > 0 and d["mlp_precision"] == "f16x2"
+    assert d["config"]["frames_per_step"] == 9 and d["config"]["frames_per_call"] == 3 and "f32+h16x2" in d["other_mlp_precisions"]
+    assert d["roofline"]["bound"] == "hbm" and 0 < d["roofline"]["frac"] < 1
+    assert set(d["roofline"]["hash_lookup_hbm_frac"]) == {"f32_table_1024B", "f16_table_512B"}
+    assert "one communicator, one issuing thread" in d["comm"]["design"] and d["comm"]["timeout_s"] > 0
     o = d["other_scaling"]
     assert o["scaling"] == "weak" and o["frames_per_step"] == 18 and o["value"] > 0
     assert d["comm"]["ranks"] == 2 and d["comm"]["schedule_allreduces_last_call"] >= 3
