@@ -572,6 +572,35 @@ def main():
             "equal_to_staged": bool(out[3] == ref[3] and all(torch.equal(out[i], ref[i]) for i in range(3))),
             "note": "cednerf.utils.render_image (eval, utils.py:46-150) on frame 0, one GPU; staged = sampling over every "
                     "marched sample with sigma_fn, then rendering (the reference's composition on the same kernels)"}
+    # the viewer's operating point (gui.py:203-237): ONE frame, rays generated on the device from the pose, max_samples = 200,
+    # the reference's fp16 networks (mode f16) -- and the timed mode beside it
+    gui_entry = None
+    if not args.no_single_frame:
+        from ced_nerf_amd import cameras
+        from ced_nerf_amd.utils import render_image_test as _rit
+        focal = 0.5 * args.width / np.tan(0.5 * cfg["camera_angle_x"])
+        K_ = np.array([[focal, 0, args.width / 2.0], [0, focal, args.height / 2.0], [0, 0, 1]], np.float32)
+        c2w_ = np.ascontiguousarray(S.look_at_c2w(cfg["radius"], 30.0, 30.0, cfg["opengl"]), dtype=np.float32)
+        K_t = K_
+        gui_entry = {"max_samples": 200, "note": "gui.py:203-237: pose -> rays on the device (ced_generate_rays_pinhole) -> "
+                                                  "render_image_test(max_samples=200), one frame at a time, median of 20"}
+        for prec in dict.fromkeys(["f16", args.mlp_precision]):
+            field.set_mlp_precision(prec)
+            field._descriptor()
+            tms, tot = [], 0
+            for it_ in range(23):
+                torch.cuda.synchronize()
+                t1 = time.perf_counter()
+                r_ = cameras.pinhole_rays(K_t, c2w_, args.width, args.height, cfg["opengl"], device=dev)
+                o_ = _rit(200, field, est, r_, timestamps=ts, **rk)
+                torch.cuda.synchronize()
+                if it_ >= 3:
+                    tms.append((time.perf_counter() - t1) * 1e3)
+                tot = int(o_[3])
+            gui_entry[prec] = {"ms_per_frame": float(np.median(tms)), "p90": float(np.quantile(tms, 0.9)), "samples": tot,
+                               "fps": 1e3 / float(np.median(tms))}
+        field.set_mlp_precision(args.mlp_precision)
+        field._descriptor()
     fp16 = sc["params"]["hash"]["table"].dtype == np.float16
     line = {
         "metric": "samples_per_sec (render_image_test, 800x800 D-NeRF lego-shaped synthetic)",
@@ -584,7 +613,7 @@ def main():
         "rays_per_sec": n_rays_step * args.steps / dt,
         "ms_per_frame": 1e3 * dt / args.steps / n_frames,
         "single_frame_latency_ms": single_ms, "single_frame_latency_stats_ms": single_stats,
-        "render_image": render_image_entry,
+        "render_image": render_image_entry, "gui_operating_point": gui_entry,
         "windows": {"n": len(window_rates), "steps_each": args.steps, "seconds": timed, "unit": "samples/s",
                     "median": float(np.median(window_rates)), "p10": float(np.quantile(window_rates, 0.1)),
                     "p90": float(np.quantile(window_rates, 0.9)), "first": window_rates[0],

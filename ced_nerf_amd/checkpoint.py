@@ -150,8 +150,10 @@ def load_reference_checkpoint(path_or_state, radiance_field, estimator=None, *, 
     into modules of this package constructed with the same flags (train_real.py:252-265).  See the module docstring:
     the tcnn layout is an unverified hypothesis and must be named explicitly."""
     _require_layout(assume_tcnn_layout)
-    ckpt = torch.load(path_or_state, map_location=map_location) if isinstance(path_or_state, (str, bytes)) or hasattr(
-        path_or_state, "read") else path_or_state
+    # weights_only: the reference's checkpoints hold tensors and python scalars only (train_real.py:433-441); never run a
+    # pickle's code for them
+    ckpt = torch.load(path_or_state, map_location=map_location, weights_only=True) if isinstance(path_or_state, (str, bytes)) \
+        or hasattr(path_or_state, "read") else path_or_state
     sd = ckpt["radiance_field"] if "radiance_field" in ckpt else ckpt
     cfg = radiance_field.hash_cfg
     if radiance_field.hash_table.dtype != torch.float32 and radiance_field.hash_table.dtype != torch.float16:
@@ -173,3 +175,89 @@ def load_reference_checkpoint(path_or_state, radiance_field, estimator=None, *, 
     if estimator is not None and "occupancy_grid" in ckpt:
         occ = {k: v for k, v in ckpt["occupancy_grid"].items() if k in ("resolution", "aabbs", "occs", "binaries")}
         estimator.load_state_dict(occ, strict=False)
+
+
+# ----------------------------------------------------------------------------------------------------------------------
+# A falsifiability gate for the layout hypothesis (tools/verify_checkpoint.py)
+# ----------------------------------------------------------------------------------------------------------------------
+@torch.no_grad()
+def checkpoint_consistency(radiance_field, estimator, timestamps: Optional[torch.Tensor] = None, render_step_size: float = 5e-3,
+                           occ_thre: float = 1e-2, n_cells: int = 20000, seed: int = 0, points_per_cell: int = 4) -> Dict:
+    """Does the loaded FIELD agree with the loaded OCCUPANCY GRID?  The two halves of a `model.pth` are stored
+    independently (train_real.py:433-441): the grid's `binaries` were thresholded from the field's own density during
+    training (`occ_eval_fn`, train_real.py:324-336: density(x, t) * render_step_size against `occ_thre`).  Under the right
+    parameter layout the field is dense where the grid says occupied and empty where it says free; under a wrong one
+    (levels permuted, a matrix transposed, features swapped) the density has no relation to the grid and the two rates
+    below coincide.  Nothing here needs the training data.
+
+    Per grid level, `n_cells` occupied and `n_cells` free cells are drawn; the density is evaluated at `points_per_cell`
+    points of each cell (the centre and jittered points, as the trainer's `_update` samples cells at random positions) at
+    each of `timestamps` (default 0, 0.25, .., 1), and the maximum over points and time is compared with `occ_thre` as the
+    trainer did.
+      hit_rate_occupied   fraction of occupied cells whose density * step exceeds the threshold
+      hit_rate_free       the same for free cells
+      separation          hit_rate_occupied - hit_rate_free     (1: perfect agreement, ~0: unrelated)
+      auc                 P(density of a random occupied cell > density of a random free cell)   (0.5: unrelated)
+    plus range statistics of sigma and rgb at the sampled points (a dead or saturated network shows here).
+    `verdict`: "consistent" (separation >= 0.5 and auc >= 0.8), "inconsistent" (separation < 0.2 or auc < 0.65), else "unclear"."""
+    dev = radiance_field.hash_table.device
+    g = torch.Generator(device="cpu").manual_seed(seed)
+    ts = timestamps if timestamps is not None else torch.linspace(0.0, 1.0, 5)
+    ts = ts.reshape(-1).to(dev, torch.float32)
+    binaries = estimator.binaries                       # [levels, R, R, R] bool
+    aabbs = estimator.aabbs.to(dev)
+    levels, R = binaries.shape[0], binaries.shape[1]
+    out_levels, occ_all, free_all, sig_all, rgb_all = [], [], [], [], []
+    for lvl in range(levels):
+        flat = binaries[lvl].reshape(-1).to(dev)
+        idx_occ = torch.nonzero(flat).reshape(-1)
+        idx_free = torch.nonzero(~flat).reshape(-1)
+        if idx_occ.numel() == 0 or idx_free.numel() == 0:
+            out_levels.append({"level": lvl, "occupied_cells": int(idx_occ.numel()), "skipped": "one class is empty"})
+            continue
+        pick = lambda idx: idx[torch.randint(0, idx.numel(), (min(n_cells, idx.numel()),), generator=g).to(dev)]  # noqa: E731
+        dens = {}
+        for name, idx in (("occ", pick(idx_occ)), ("free", pick(idx_free))):
+            ijk = torch.stack([idx // (R * R), (idx // R) % R, idx % R], dim=-1).to(torch.float32)
+            best = torch.zeros(ijk.shape[0], device=dev)
+            for k in range(max(1, points_per_cell)):
+                off = 0.5 if k == 0 else torch.rand(ijk.shape[0], 3, generator=g).to(dev)
+                x = aabbs[lvl, :3] + (ijk + off) / R * (aabbs[lvl, 3:] - aabbs[lvl, :3])
+                for t in ts:
+                    tt = t.expand(x.shape[0], 1).contiguous()
+                    d = radiance_field.query_density(x.contiguous(), tt)["density"].reshape(-1)
+                    best = torch.maximum(best, d)
+            dens[name] = best
+            sig_all.append(best)
+        dirs = torch.nn.functional.normalize(torch.randn(dens["occ"].shape[0], 3, generator=g), dim=-1).to(dev)
+        idx = pick(idx_occ)[:dirs.shape[0]]
+        ijk = torch.stack([idx // (R * R), (idx // R) % R, idx % R], dim=-1).to(torch.float32)
+        x = aabbs[lvl, :3] + (ijk + 0.5) / R * (aabbs[lvl, 3:] - aabbs[lvl, :3])
+        rgb, _ = radiance_field(x[:dirs.shape[0]].contiguous(), ts[:1].expand(dirs.shape[0], 1).contiguous(), dirs[:x.shape[0]].contiguous())
+        rgb_all.append(rgb)
+        hit_o = float((dens["occ"] * render_step_size > occ_thre).float().mean())
+        hit_f = float((dens["free"] * render_step_size > occ_thre).float().mean())
+        # AUC by ranks (ties count half)
+        both = torch.cat([dens["occ"], dens["free"]])
+        ranks = torch.empty_like(both)
+        order = torch.argsort(both)
+        ranks[order] = torch.arange(1, both.numel() + 1, device=dev, dtype=both.dtype)
+        n_o, n_f = dens["occ"].numel(), dens["free"].numel()
+        auc = float((ranks[:n_o].sum() - n_o * (n_o + 1) / 2.0) / (n_o * n_f))
+        out_levels.append({"level": lvl, "occupied_cells": int(idx_occ.numel()), "free_cells": int(idx_free.numel()),
+                           "hit_rate_occupied": hit_o, "hit_rate_free": hit_f, "separation": hit_o - hit_f, "auc": auc})
+        occ_all.append(dens["occ"]); free_all.append(dens["free"])
+    scored = [l for l in out_levels if "separation" in l]
+    if not scored:
+        return {"levels": out_levels, "verdict": "unclear", "reason": "no grid level has both occupied and free cells"}
+    sep = min(l["separation"] for l in scored)
+    auc = min(l["auc"] for l in scored)
+    sig = torch.cat(sig_all); rgb = torch.cat(rgb_all)
+    q = lambda t, p: float(torch.quantile(t.float().reshape(-1)[:1_000_000], p))  # noqa: E731
+    verdict = "consistent" if (sep >= 0.5 and auc >= 0.8) else ("inconsistent" if (sep < 0.2 or auc < 0.65) else "unclear")
+    return {"levels": out_levels, "separation_min": sep, "auc_min": auc, "verdict": verdict,
+            "sigma": {"min": float(sig.min()), "p50": q(sig, 0.5), "p99": q(sig, 0.99), "max": float(sig.max()),
+                      "fraction_zero": float((sig == 0).float().mean()), "finite": bool(torch.isfinite(sig).all())},
+            "rgb": {"min": float(rgb.min()), "mean": float(rgb.mean()), "max": float(rgb.max()), "std": float(rgb.std()),
+                    "finite": bool(torch.isfinite(rgb).all())},
+            "render_step_size": render_step_size, "occ_thre": occ_thre, "timestamps": [float(v) for v in ts]}

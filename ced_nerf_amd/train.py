@@ -8,7 +8,10 @@ What runs where:
   * the bias-free MLPs (motion, base, head, prediction heads) -> HIP  in both directions, no library GEMM:
     y = relu(x W^T) and dx = (dz W) * relu' through ced_linear (csrc/linear.hip), dW = dz^T x through ced_weight_grad
     (csrc/wgrad.hip); `_MlpFn` strings them into one autograd node per MLP.
-    Encodings and the small element-wise pieces (sin, exp, sigmoid, huber) are torch element-wise kernels.
+  * the pieces between the MLPs (sample positions + Frequency / SH encodings; move / normalise / selector; trunc_exp and
+    the head's input) -> HIP, one launch per direction each (ced_train_inputs / _warp / _head_in, csrc/train_glue.hip;
+    `fused_glue = False` restores the torch statements they replaced, which the tests compare them with).  Only the
+    sigmoid, the time encoders and the losses (huber, smooth-L1) remain torch element-wise kernels.
 `TrainableField` keeps the parameter names and layout of `DNGPradianceField` (hash_table, xyz_wrap, mlp_base,
 mlp_head as W[out][in]), so `to_inference()` hands the trained weights to the fused kernels unchanged, and
 `tests/test_gpu_parity.py` checks that the two forwards agree.  Mirrors cednerf/model.py:354-488 (forward) and the
@@ -299,8 +302,12 @@ class TrainableField(torch.nn.Module):
         return self._forward_core(pos, enc, sh, tt, return_internal)
 
     def _forward_core(self, pos, enc, sh, tt, return_internal):
-        if getattr(self, "_aabb6", None) is None:
+        # the box as python floats for the fused warp kernel, re-read whenever the buffer is replaced or written in place
+        # (load_state_dict, a checkpoint load, aabb.copy_): keyed like DNGPradianceField._descriptor
+        key = (self.aabb.data_ptr(), self.aabb._version)
+        if getattr(self, "_aabb6_key", None) != key:
             object.__setattr__(self, "_aabb6", [float(v) for v in self.aabb.detach().cpu().tolist()])
+            object.__setattr__(self, "_aabb6_key", key)
         mo = self._mlp(enc, list(self.xyz_wrap))
         xn, move, sel = _WarpFn.apply(pos, mo, self._aabb6, self.moving_step, self.use_div_offsets)   # model.py:356-383
         hash_feat = feat = _HashFn.apply(xn, self.hash_table, self.hash_cfg)

@@ -1515,6 +1515,103 @@ def test_reference_checkpoint_renders_the_same_frame(oracle, tmp_path):
     assert (got[0] - want[0]).abs().max().item() <= 1e-5
 
 
+@pytest.mark.parametrize("prec", ["f16", "f16x2"])
+def test_gui_operating_point(oracle, prec):
+    """The viewer's frame (gui.py:203-237): `render_image_test` with max_samples = 200 under fp16 autocast (the reference's
+    tcnn networks evaluate in fp16: mode f16; f16x2 is this package's fp32-grade form of it), rays generated on the device
+    from the camera pose.  The sample budget binds here (the loop ends on `max_samples`, not on dead rays): schedule,
+    totals and every pixel against the oracle's mode of the same name, bit for bit."""
+    from ced_nerf_amd import cameras, ops
+    from ced_nerf_amd.utils import render_image_test
+    W, H = 160, 120
+    sc = _scene("dnerf", W, H, "trained", log2_hashmap_size=17)
+    of, oest, f, est, rays, rk = _setup(oracle, sc)
+    cfg = sc["cfg"]
+    f.set_mlp_precision(prec)
+    focal = 0.5 * W / np.tan(0.5 * cfg["camera_angle_x"])
+    K = np.array([[focal, 0, W / 2.0], [0, focal, H / 2.0], [0, 0, 1]], np.float32)
+    c2w = S_look_at(cfg)
+    r = cameras.pinhole_rays(K, c2w, W, H, cfg["opengl"], device=DEV)
+    o_np, d_np = N(r.origins), N(r.viewdirs)
+    ts = torch.tensor([[0.0]], device=DEV)                      # gui.py:200: the viewer starts at t = 0
+    ofm = oracle.OracleField(sc["params"], mlp_half=prec)
+    totals = {}
+    for max_samples in (200, 1024):
+        trace = []
+        want = oracle.render_image_test(max_samples, ofm, oest, o_np, d_np, timestamps=N(ts), trace=trace, **sc["render"])
+        tracer = ops.FrameTracer(capacity=1100, with_events=False)
+        got = render_image_test(max_samples, f, est, r, timestamps=ts, tracer=tracer, **rk)
+        assert got[3] == want[3] > 1000
+        assert tracer.iterations() == [dict(n_alive=t["n_alive"], n_samples=t["n_samples"], n_new=t["n_new"]) for t in trace]
+        for nm, g_, w_ in (("rgb", got[0], want[0]), ("opacity", got[1], want[1]), ("depth", got[2], want[2])):
+            assert_bitexact(N(g_), w_, f"gui frame {prec} max_samples={max_samples} {nm}")
+        totals[max_samples] = (got[3], sum(t["n_samples"] for t in trace))
+    # at 200 the loop ends on the budget (cednerf/utils.py:230), with rays still alive: fewer samples than at 1024
+    assert totals[200][1] >= 200 and totals[200][0] < totals[1024][0], totals
+
+
+def S_look_at(cfg):
+    from ced_nerf_amd import synthetic as S
+    return S.look_at_c2w(cfg["radius"], 25.0, 75.0, cfg["opengl"])
+
+
+def test_checkpoint_consistency_gate_flags_a_wrong_layout(tmp_path):
+    """tools/verify_checkpoint.py's core (checkpoint.checkpoint_consistency): a `model.pth` whose occupancy grid was
+    thresholded from the field's own density (as the reference's trainer does, train_real.py:324-336) loads as "consistent"
+    under the documented layout; the same file with the hash levels' blocks rotated, with mlp_base's matrices transposed,
+    or with its two halves taken from different models loads without any error -- and is flagged: the numbers fall to
+    chance.  This is the check a user with a real reference checkpoint can run; no training data needed."""
+    from ced_nerf_amd import checkpoint as CK, synthetic as S
+    from ced_nerf_amd.hashgrid import level_tables
+    from ced_nerf_amd.model import DNGPradianceField, make_occ_eval_fn
+    from ced_nerf_amd.nerfacc_api import OccGridEstimator
+    cfg = S.CONFIGS["dnerf"]
+    p = S.init_field_params(cfg["aabb"], cfg["moving_step"], cfg["hash_max_res"], 15, regime="trained", seed=5)
+    lv = level_tables(16, cfg["hash_max_res"], 16, 15)
+    tab = p["hash"]["table"].copy()
+    tab[int(lv["offset"][5]):] *= 0.02                       # a scene-like density: smooth at the scale of a grid cell
+    p["hash"]["table"] = tab
+    f = DNGPradianceField.from_params(p, DEV).eval()
+    est = OccGridEstimator(cfg["aabb"], cfg["grid_resolution"], cfg["grid_levels"]).to(DEV)
+    occ_eval_fn = make_occ_eval_fn(f, torch.linspace(0, 1, 5, device=DEV)[:, None], cfg["render_step_size"])
+    for step in range(4):
+        est._update(step, occ_eval_fn, occ_thre=1e-2)
+    frac = float(est.binaries.float().mean())
+    assert 0.05 < frac < 0.95, frac
+
+    def load(state, grid):
+        f2 = DNGPradianceField(aabb=cfg["aabb"], dst_resolution=cfg["hash_max_res"], log2_hashmap_size=15,
+                               moving_step=cfg["moving_step"], seed=11).to(DEV).eval()
+        e2 = OccGridEstimator(cfg["aabb"], cfg["grid_resolution"], cfg["grid_levels"]).to(DEV)
+        path = str(tmp_path / "model.pth")
+        torch.save({"radiance_field": state, "occupancy_grid": grid}, path)
+        CK.load_reference_checkpoint(path, f2, e2, assume_tcnn_layout=CK.TCNN_LAYOUT)
+        return CK.checkpoint_consistency(f2, e2, render_step_size=cfg["render_step_size"], n_cells=6000)
+
+    good = CK.reference_state_from_field(f)
+    rep = load(good, est.state_dict())
+    print("right layout:", {k: rep[k] for k in ("separation_min", "auc_min", "verdict")}, rep["sigma"])
+    assert rep["verdict"] == "consistent" and rep["separation_min"] >= 0.5 and rep["auc_min"] >= 0.8, rep
+    assert rep["sigma"]["finite"] and rep["rgb"]["finite"] and 0 < rep["rgb"]["std"]
+    # (1) the hash table's level blocks rotated by one level (a level-major / level-size misunderstanding)
+    bad = dict(good)
+    hp = good["hash_encoder.params"].clone()
+    bad["hash_encoder.params"] = torch.roll(hp, int(lv["size"][0]) * 2)
+    # (2) mlp_base's matrices stored [in][out] instead of [out][in]
+    bad2 = dict(good)
+    mats, _ = CK.split_tcnn_mlp(good["mlp_base.params"], 32, 16, 1)
+    bad2["mlp_base.params"] = CK.join_tcnn_mlp([np.ascontiguousarray(mats[0].T).reshape(mats[0].shape),
+                                                 np.ascontiguousarray(mats[1].T).reshape(mats[1].shape)])
+    # (3) a grid that belongs to another model
+    other = OccGridEstimator(cfg["aabb"], cfg["grid_resolution"], cfg["grid_levels"]).to(DEV)
+    other.set_binaries(T(S.make_occupancy(cfg["aabb"], cfg["grid_resolution"], cfg["grid_levels"])))
+    for name, state, grid in (("rotated hash levels", bad, est.state_dict()), ("transposed mlp_base", bad2, est.state_dict()),
+                              ("foreign grid", good, other.state_dict())):
+        r = load(state, grid)
+        print(name + ":", {k: r.get(k) for k in ("separation_min", "auc_min", "verdict")})
+        assert r["verdict"] != "consistent" and r["separation_min"] < 0.35 and r["separation_min"] < rep["separation_min"] - 0.3, (name, r)
+
+
 def test_scatter_pixels_unpermutes_and_converts(oracle):
     """ced_scatter_pixels: rows in marching / gather order -> raster images, padding rows dropped, and the 8-bit colour
     frame of train_real.py:556 in the same pass (bit-exact against numpy)."""

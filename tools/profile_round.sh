@@ -3,12 +3,13 @@
 # profiles/).  Counters are collected in their own passes (never together with trace domains).
 # usage (on the GPU box): bash tools/profile_round.sh [tag]
 set -e
-TAG=${1:-r03_final}
+TAG=${1:-r04_final}
 R=$GRAFT_REPO_ROOT
 OUT=$R/gpurun_out/prof
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
-for prec in ${MODES:-f32+h16x2 f32}; do
+export CED_BENCH_OTHER_TABLE=0      # profiled runs: only the timed table type's kernels
+for prec in ${MODES:-f16x2 f32+h16x2}; do
   ARGS="$R/bench.py --steps 5 --warmup 1 --no-cpu-baseline --also= --min-seconds 0 --mlp-precision $prec"
   # 1. the bench line itself (not under the profiler)
   timeout -k 10 300 python3 $ARGS > $OUT/${TAG}_${prec}_bench.json 2> $OUT/${TAG}_${prec}_bench.err
@@ -26,6 +27,7 @@ for prec in ${MODES:-f32+h16x2 f32}; do
   python3 $R/tools/pmc_summary.py $OUT/${TAG}_${prec}_pmc.json $OUT/pmc_fetch_$prec $OUT/pmc_write_$prec > /dev/null
   echo "pmc $prec done"
 done
-# the default bench.py line (exact mode + the fast modes + cpu baselines)
-timeout -k 10 400 python3 $R/bench.py > $OUT/${TAG}_bench_default.json 2> $OUT/${TAG}_bench_default.err
+# the default bench.py line (default mode + the other modes + cpu baselines + oracle-mode parity)
+unset CED_BENCH_OTHER_TABLE
+timeout -k 10 600 python3 $R/bench.py > $OUT/${TAG}_bench_default.json 2> $OUT/${TAG}_bench_default.err
 echo "default bench done"
