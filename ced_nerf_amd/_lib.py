@@ -92,6 +92,7 @@ PROTOTYPES = {
                                        _i32, _vp, _vp, _vp, _vp]),
     "ced_hash_encode": (C.c_int, [C.POINTER(HashDesc), _i64, _vp, _vp, _vp, _vp]),
     "ced_hash_encode_backward": (C.c_int, [C.POINTER(HashDesc), _i64, _vp, _vp, _vp, _vp, _i32, _vp]),
+    "ced_hash_encode_backward_temporal": (C.c_int, [C.POINTER(HashDesc), _i64, _vp, _vp, _vp, _vp, _vp]),
     "ced_field_forward": (C.c_int, [C.POINTER(FieldDesc), _i64, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "ced_field_forward_rays": (C.c_int, [C.POINTER(FieldDesc), _i64, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i32, _i32,
                                          _vp, _vp, _vp]),

@@ -86,6 +86,7 @@ __global__ __launch_bounds__(256) void hash_encode_kernel(HashArgs A)
 struct HashBwdArgs {
     int64_t n;
     const float *x, *dy;
+    const float *t;              // temporal tables: the sample times (hash_table_grad_temporal_kernel)
     float *grad_table, *dx;
     int n_levels, table_dtype, dx_scaled;
     const void *table;
@@ -160,6 +161,76 @@ __global__ __launch_bounds__(256) void hash_table_grad_kernel(HashBwdArgs A)
         const uint32_t next = __shfl_down(idx, 4, 64);
         const bool last = lane >= 60 || next != idx;
         if (last && idx != 0xffffffffu && v != 0.0f) unsafeAtomicAdd(A.grad_table + (size_t)idx * 2 + feat, v);
+    }
+  }
+}
+
+// Table gradient of the TEMPORAL table (entry = 4 key-frames x 2 features, hash_encoder_inter.py:202-275): a sample at time
+// t interpolates the key-frames k and k + 1 (k = min(floor(3 t), 2), weight t_frac = 3 t - floor(3 t): the reference's
+// own arithmetic, t = 1 included), so its gradient lands in FOUR contiguous floats of every corner's entry:
+// [2k + f] += w dy_f (1 - t_frac), [2k + 2 + f] += w dy_f t_frac.  Four adjacent lanes = those four floats (one 16-byte
+// request per corner), eight corners per lane, one level per blockIdx.y; runs of consecutive samples that meet the same
+// entry AND the same key-frame pair are summed across the wave first, as in hash_table_grad_kernel.
+__global__ __launch_bounds__(256) void hash_table_grad_temporal_kernel(HashBwdArgs A)
+{
+  for (int64_t gid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; gid - threadIdx.x < 4 * A.n;
+       gid += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t i = gid >> 2;
+    const int feat = (int)(gid & 1), up = (int)((gid >> 1) & 1);
+    const int l = (int)blockIdx.y;
+    const int lane = threadIdx.x & 63;
+    uint32_t pend_slot[8];          // float index of this lane's slot in the table: entry * 8 + 2 * (k + up) + feat
+    float pend_val[8];
+#pragma unroll
+    for (int c = 0; c < 8; ++c) { pend_slot[c] = 0xffffffffu; pend_val[c] = 0.0f; }
+    if (i < A.n) {
+        const float g0 = A.dy[(i * A.n_levels + l) * 2], g1 = A.dy[(i * A.n_levels + l) * 2 + 1];
+        if (g0 != 0.0f || g1 != 0.0f) {
+            int k_lo;
+            float t_frac;
+            temporal_keyframe(A.t[i], k_lo, t_frac);
+            const float tw = up ? t_frac : 1.0f - t_frac;
+            const float sc = A.scale[l];
+            uint32_t g[3];
+            float fr[3], om[3];
+#pragma unroll
+            for (int a = 0; a < 3; ++a) {
+                const float xa = __builtin_fminf(__builtin_fmaxf(A.x[3 * i + a], 0.0f), 1.0f);
+                const float pos = xa * sc + 0.5f;
+                const float fl = __builtin_floorf(pos);
+                g[a] = (uint32_t)fl;
+                fr[a] = pos - fl;
+                om[a] = 1.0f - fr[a];
+            }
+            const uint32_t res = A.res[l], size = A.size[l], off = A.offset[l];
+            const bool hashed = A.hashed[l] != 0;
+            const float gv = feat ? g1 : g0;
+#pragma unroll
+            for (int c = 0; c < 8; ++c) {
+                const uint32_t px = g[0] + (c & 1), py = g[1] + ((c >> 1) & 1), pz = g[2] + (c >> 2);
+                const float wx = (c & 1) ? fr[0] : om[0], wy = (c & 2) ? fr[1] : om[1], wz = (c & 4) ? fr[2] : om[2];
+                const float w = (wx * wy) * wz;                          // the forward's weight
+                const uint32_t idx = hashed ? (px ^ (py * 2654435761u) ^ (pz * 805459861u)) : (px + py * res + pz * res * res);
+                pend_slot[c] = (off + idx % size) * 8u + 2u * (uint32_t)(k_lo + up) + (uint32_t)feat;
+                pend_val[c] = (w * gv) * tw;                             // (w * dy) * (1 - t_frac | t_frac), :264-267
+            }
+        }
+    }
+#pragma unroll
+    for (int c = 0; c < 8; ++c) {
+        const uint32_t slot = pend_slot[c];
+        float v = pend_val[c];
+        const uint32_t prev = __shfl_up(slot, 4, 64);
+        int head = (lane < 4 || prev != slot) ? 1 : 0;
+#pragma unroll
+        for (int d = 4; d < 64; d <<= 1) {
+            const float v_up = __shfl_up(v, d, 64);
+            const int h_up = __shfl_up(head, d, 64);
+            if (lane >= d && !head) { v += v_up; head |= h_up; }
+        }
+        const uint32_t next = __shfl_down(slot, 4, 64);
+        const bool last = lane >= 60 || next != slot;
+        if (last && slot != 0xffffffffu && v != 0.0f) unsafeAtomicAdd(A.grad_table + (size_t)slot, v);
     }
   }
 }
@@ -599,4 +670,30 @@ extern "C" int ced_hash_encode_backward(const ced_hash_desc *desc, int64_t n, co
         else hipLaunchKernelGGL((ced::hash_backward_kernel<false, false>), grid_x, block, 0, (hipStream_t)stream, A);
     }
     return ced::check_launch("hash_encode_backward");
+}
+
+extern "C" int ced_hash_encode_backward_temporal(const ced_hash_desc *desc, int64_t n, const float *x, const float *t,
+                                                 const float *dy, float *grad_table, void *stream)
+{
+    int rc = ced::validate_hash(desc, "hash_encode_backward_temporal");
+    if (rc) return rc;
+    CED_REQUIRE(n >= 0, "hash_encode_backward_temporal: n < 0");
+    CED_REQUIRE(desc->temporal, "hash_encode_backward_temporal: the table is not temporal (use ced_hash_encode_backward)");
+    CED_REQUIRE(desc->n_levels <= 16, "hash_encode_backward_temporal: n_levels > 16");
+    CED_REQUIRE(desc->total_entries * 8ull < (1ull << 32), "hash_encode_backward_temporal: table too large for 32-bit slots");
+    if (n == 0) return CED_OK;
+    CED_REQUIRE(x && t && dy && grad_table, "hash_encode_backward_temporal: null pointer");
+    ced::HashBwdArgs A{};
+    A.n = n; A.x = x; A.t = t; A.dy = dy; A.grad_table = grad_table;
+    A.n_levels = desc->n_levels; A.table_dtype = desc->table_dtype; A.table = desc->table;
+    for (int l = 0; l < CED_MAX_LEVELS; ++l) {
+        A.scale[l] = desc->scale[l]; A.res[l] = desc->res[l]; A.offset[l] = desc->offset[l];
+        A.size[l] = desc->size[l]; A.hashed[l] = desc->hashed[l];
+    }
+    int64_t gx = (4 * n + 255) / 256;
+    const int cap = ced::g_hash_grad_blocks;
+    if (cap > 0 && gx > cap) gx = cap;
+    hipLaunchKernelGGL(ced::hash_table_grad_temporal_kernel, dim3((unsigned)gx, (unsigned)desc->n_levels), dim3(256), 0,
+                       (hipStream_t)stream, A);
+    return ced::check_launch("hash_encode_backward_temporal");
 }

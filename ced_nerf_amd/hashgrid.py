@@ -105,3 +105,47 @@ class _HashEncodeFunction(torch.autograd.Function):
                                                   want_dx=ctx.needs_input_grad[0],
                                                   dx_scaled=ctx.module.true_position_gradient)
         return dx, grad_table, None
+
+
+class TemporalHashEncoder(HashEncoder):
+    """The reference's temporal `HashEncoder` (cednerf/taichi_kernel/hash_encoder_inter.py:281-430): entries hold four
+    key-frames x two features, `forward(xyzt [N,4])` interpolates the key-frames k, k + 1 of t linearly (k = min(floor(3t),
+    2)) before the trilinear sum, and the backward yields the TABLE gradient only (:202-275, :403-420: positions and
+    times get none).  Same HIP kernels as the fused field's `temporal_hash=True`."""
+
+    def __init__(self, max_params: float = 2 ** 19, levels: int = 16, base_res: float = 16.0, max_res: float = 2048.0,
+                 feature_per_level: int = 2, device="cuda"):
+        super().__init__(max_params, levels, base_res, max_res, feature_per_level, device)
+        total = self.hash_table.shape[0]
+        table = torch.empty((total, 8), dtype=torch.float32, device=device).uniform_(-1e-4, 1e-4)
+        self.hash_table = torch.nn.Parameter(table, requires_grad=True)
+
+    def _desc(self, table):
+        from . import ops
+        d, _ = ops.make_hash_desc(table, self.cfg["base_res"], self.cfg["max_res"], self.cfg["n_levels"],
+                                  self.cfg["log2_hashmap_size"], True)
+        return d
+
+    def forward(self, xyzt: torch.Tensor) -> torch.Tensor:
+        xyzt = xyzt.reshape(-1, 4).float()
+        return _TemporalHashEncodeFunction.apply(xyzt[:, :3].contiguous(), xyzt[:, 3].contiguous(), self.hash_table, self)
+
+
+class _TemporalHashEncodeFunction(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, t, table, module):
+        from . import ops
+        if x.device.type != "cuda":
+            raise NotImplementedError("Only support cuda inputs.")
+        tab = table.detach().contiguous()
+        out = ops.hash_encode(module._desc(tab), x.detach(), t.detach())
+        ctx.save_for_backward(x.detach(), t.detach(), tab)
+        ctx.module = module
+        return out
+
+    @staticmethod
+    def backward(ctx, dy):
+        from . import ops
+        x, t, tab = ctx.saved_tensors
+        grad_table = ops.hash_encode_backward_temporal(ctx.module._desc(tab), x, t, dy.float().contiguous())
+        return None, None, grad_table, None

@@ -201,6 +201,24 @@ def hash_encode_backward(desc: _lib.HashDesc, x: torch.Tensor, dy: torch.Tensor,
     return grad_table, dx
 
 
+def hash_encode_backward_temporal(desc: _lib.HashDesc, x: torch.Tensor, t: torch.Tensor, dy: torch.Tensor,
+                                  grad_table: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """ced_hash_encode_backward_temporal (hash_encoder_inter.py:202-275): grad_table [E, 8] fp32, accumulated into when
+    given.  The temporal encoder has a table gradient only (the reference's autograd function returns none for positions)."""
+    _chk(x, torch.float32, "x"); _chk(dy, torch.float32, "dy"); _chk(t, torch.float32, "t")
+    n = x.shape[0]
+    assert desc.temporal, "not a temporal table"
+    assert x.shape == (n, 3) and t.numel() == n and dy.numel() == n * 2 * desc.n_levels, f"{x.shape} {t.shape} {dy.shape}"
+    if grad_table is None:
+        grad_table = torch.zeros((int(desc.total_entries), 8), device=x.device, dtype=torch.float32)
+    else:
+        _chk(grad_table, torch.float32, "grad_table")
+        assert grad_table.shape == (int(desc.total_entries), 8)
+    rc = _lib.lib().ced_hash_encode_backward_temporal(C.byref(desc), n, _p(x), _p(t), _p(dy), _p(grad_table), _stream())
+    _lib.check(rc, "hash_encode_backward_temporal")
+    return grad_table
+
+
 def field_forward(desc: _lib.FieldDesc, positions, t, directions=None, want_geo=False):
     _chk(positions, torch.float32, "positions"); _chk(t, torch.float32, "t")
     n = positions.shape[0]

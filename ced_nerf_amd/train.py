@@ -33,12 +33,21 @@ from .utils import trunc_exp
 
 
 class _HashFn(torch.autograd.Function):
+    """Hash-grid encode with the gradient of hash_encoder_half.py:164-226 (table and positions), or -- temporal tables --
+    of hash_encoder_inter.py:202-275 (table only: the reference's temporal encoder gives positions no gradient).
+    `table` is the fp32 master parameter; `table_eval` (optional) is what the kernels READ: the fp16 copy of an fp16-table
+    field (tiny-cuda-nn keeps fp32 master parameters and evaluates on their fp16 copy).  Gradients are accumulated in
+    fp32 either way."""
+
     @staticmethod
-    def forward(ctx, x, table, cfg):
-        tab = table.detach().contiguous()
-        desc, _ = ops.make_hash_desc(tab, cfg["base_res"], cfg["max_res"], cfg["n_levels"], cfg["log2_hashmap_size"], False)
-        out = ops.hash_encode(desc, x.detach().contiguous())
-        ctx.save_for_backward(x.detach().contiguous(), tab)
+    def forward(ctx, x, table, cfg, t=None, table_eval=None):
+        tab = (table_eval if table_eval is not None else table).detach().contiguous()
+        temporal = bool(cfg.get("temporal", False))
+        desc, _ = ops.make_hash_desc(tab, cfg["base_res"], cfg["max_res"], cfg["n_levels"], cfg["log2_hashmap_size"], temporal)
+        xc = x.detach().contiguous()
+        tc = t.detach().reshape(-1).float().contiguous() if temporal else None
+        out = ops.hash_encode(desc, xc, tc)
+        ctx.save_for_backward(xc, tab, tc if tc is not None else xc.new_zeros(0))
         ctx.cfg = cfg
         return out
 
@@ -52,16 +61,26 @@ class _HashFn(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, dy):
-        x, tab = ctx.saved_tensors
+        x, tab, tc = ctx.saved_tensors
         cfg = ctx.cfg
-        desc, _ = ops.make_hash_desc(tab, cfg["base_res"], cfg["max_res"], cfg["n_levels"], cfg["log2_hashmap_size"], False)
+        temporal = bool(cfg.get("temporal", False))
+        desc, _ = ops.make_hash_desc(tab, cfg["base_res"], cfg["max_res"], cfg["n_levels"], cfg["log2_hashmap_size"], temporal)
         dy = dy.float().contiguous()
         d = _HashFn.deferred
+        width = 8 if temporal else 2
+
+        def table_grad(into=None):
+            if temporal:
+                return ops.hash_encode_backward_temporal(desc, x, tc, dy, grad_table=into)
+            return ops.hash_encode_backward(desc, x, dy, grad_table=into, want_dx=False, dx_scaled=True)[0]
+
+        want_dx = ctx.needs_input_grad[0] and not temporal
         if d is None or not ctx.needs_input_grad[1] or x.shape[0] == 0:
-            grad_table, dx = ops.hash_encode_backward(desc, x, dy, want_dx=ctx.needs_input_grad[0], dx_scaled=True)
-            return dx, grad_table, None
+            grad_table = table_grad() if ctx.needs_input_grad[1] else None
+            dx = ops.hash_encode_backward(desc, x, dy, want_dx=True, dx_scaled=True, want_table=False)[1] if want_dx else None
+            return dx, grad_table, None, None, None
         main = torch.cuda.current_stream()
-        grad_table = torch.zeros((int(desc.total_entries), 2), device=x.device, dtype=torch.float32)    # main stream's pool
+        grad_table = torch.zeros((int(desc.total_entries), width), device=x.device, dtype=torch.float32)    # main stream's pool
         d["side"].wait_stream(main)
         with torch.cuda.stream(d["side"]):
             # a few workgroups per CU (the atomics are fire-and-forget): room for the MLP kernels of the main stream.
@@ -69,16 +88,16 @@ class _HashFn(torch.autograd.Function):
             # (262 k rays: 12.4 -> 11.2 ms with 24-32 workgroups per level, 11.6 with 16, 11.9 with 48).
             _lib.lib().ced_set_option(b"hash_grad_blocks", _HashFn.side_blocks_per_level)
             try:
-                ops.hash_encode_backward(desc, x, dy, grad_table=grad_table, want_dx=False, dx_scaled=True)
+                table_grad(grad_table)
             finally:
                 _lib.lib().ced_set_option(b"hash_grad_blocks", 0)
-        for t_ in (x, dy, tab):
+        for t_ in (x, dy, tab, tc):
             t_.record_stream(d["side"])                # their memory must not be handed out again before the kernel is over
         d["pending"].append(grad_table)
         dx = None
-        if ctx.needs_input_grad[0]:
+        if want_dx:
             _, dx = ops.hash_encode_backward(desc, x, dy, want_dx=True, dx_scaled=True, want_table=False)
-        return dx, None, None
+        return dx, None, None, None, None
 
 
 def begin_deferred_table_grad(device) -> None:
@@ -233,17 +252,26 @@ class TrainableField(torch.nn.Module):
                  seed: int = 0):
         super().__init__()
         h = params["hash"]
-        if h.get("temporal", False) or np.asarray(h["table"]).dtype != np.float32:
-            raise NotImplementedError("training uses the fp32, non-temporal hash table")
+        # The reference's table types (round 4): an fp16 table trains as tiny-cuda-nn does -- an fp32 MASTER parameter, an
+        # fp16 copy that the kernels evaluate (refreshed after every optimiser step, `sync_half_table`), gradients in fp32
+        # (cednerf/model.py:262-276 under train_real.py:330's autocast); the temporal table ([E, 8]: 4 key-frames x 2
+        # features) has the reference's table-only backward (hash_encoder_inter.py:202-275).
+        self.temporal = bool(h.get("temporal", False))
+        self.table_f16 = np.asarray(h["table"]).dtype == np.float16
         self.hash_cfg = dict(base_res=h["base_res"], max_res=h["max_res"], n_levels=h["n_levels"],
                              log2_hashmap_size=h["log2_hashmap_size"])
+        if self.temporal:
+            self.hash_cfg["temporal"] = True
         assert level_tables(h["base_res"], h["max_res"], h["n_levels"], h["log2_hashmap_size"])["total"] == h["table"].shape[0]
+        assert h["table"].shape[1] == (8 if self.temporal else 2)
         T = lambda a: torch.nn.Parameter(torch.from_numpy(np.ascontiguousarray(a, dtype=np.float32)).to(device))
         self.register_buffer("aabb", torch.from_numpy(np.asarray(params["aabb"], np.float32)).to(device))
         self.moving_step = float(params["moving_step"])
         self.use_div_offsets = bool(params["use_div_offsets"])
         self.time_mode = int(params["time_mode"])
-        self.hash_table = T(h["table"])
+        self.hash_table = T(h["table"])                       # fp32 master (converted exactly from an fp16 table)
+        if self.table_f16:
+            self.register_buffer("hash_table_half", self.hash_table.detach().half(), persistent=False)
         self.xyz_wrap = torch.nn.ParameterList([T(w) for w in params["xyz_wrap"]])
         self.mlp_base = torch.nn.ParameterList([T(w) for w in params["mlp_base"]])
         self.mlp_head = torch.nn.ParameterList([T(w) for w in params["mlp_head"]])
@@ -310,7 +338,7 @@ class TrainableField(torch.nn.Module):
             object.__setattr__(self, "_aabb6_key", key)
         mo = self._mlp(enc, list(self.xyz_wrap))
         xn, move, sel = _WarpFn.apply(pos, mo, self._aabb6, self.moving_step, self.use_div_offsets)   # model.py:356-383
-        hash_feat = feat = _HashFn.apply(xn, self.hash_table, self.hash_cfg)
+        hash_feat = feat = _HashFn.apply(xn, self.hash_table, self.hash_cfg, tt, self._table_eval())
         if self.time_mode:                                                          # model.py:386-403 (no gradient there)
             with torch.no_grad():
                 t1 = tt[:, None]
@@ -346,7 +374,7 @@ class TrainableField(torch.nn.Module):
             move = move + torch.tanh(mo[:, 3:6]) * self.moving_step
         xn = (x + move - self.aabb[:3]) / (self.aabb[3:] - self.aabb[:3])           # model.py:378-379
         selector = ((xn > 0.0) & (xn < 1.0)).all(dim=-1)                            # model.py:383
-        hash_feat = feat = _HashFn.apply(xn.clamp(0.0, 1.0), self.hash_table, self.hash_cfg)
+        hash_feat = feat = _HashFn.apply(xn.clamp(0.0, 1.0), self.hash_table, self.hash_cfg, tt, self._table_eval())
         if self.time_mode:                                                          # model.py:386-403 (no gradient there)
             with torch.no_grad():
                 mn = move.detach().norm(dim=-1, keepdim=True)
@@ -373,10 +401,21 @@ class TrainableField(torch.nn.Module):
                 internal["weight_losses"] = self._mlp(temp, list(self.mlp_weight_prediction))
         return rgb, {"density": sigma[:, None], "interal_output": internal}
 
+    def sync_half_table(self) -> None:
+        """fp16-table fields: refresh the evaluated fp16 copy from the fp32 master (after an optimiser step or a load).
+        In place, so that the shared inference module re-packs / re-reads it (its descriptor is keyed on tensor versions)."""
+        if self.table_f16:
+            with torch.no_grad():
+                self.hash_table_half.copy_(self.hash_table)
+
+    def _table_eval(self):
+        return self.hash_table_half if self.table_f16 else None
+
     def export_params(self) -> Dict:
         g = lambda p: p.detach().cpu().numpy()
         return dict(aabb=g(self.aabb), moving_step=self.moving_step, use_div_offsets=self.use_div_offsets,
-                    time_mode=self.time_mode, hash=dict(table=g(self.hash_table), **self.hash_cfg),
+                    time_mode=self.time_mode,
+                    hash=dict(table=g(self.hash_table).astype(np.float16) if self.table_f16 else g(self.hash_table), **self.hash_cfg),
                     xyz_wrap=[g(p) for p in self.xyz_wrap], mlp_base=[g(p) for p in self.mlp_base],
                     mlp_head=[g(p) for p in self.mlp_head])
 
@@ -395,8 +434,9 @@ class TrainableField(torch.nn.Module):
             m = DNGPradianceField(aabb=self.aabb, dst_resolution=h["max_res"], base_resolution=h["base_res"],
                                   n_levels=h["n_levels"], log2_hashmap_size=h["log2_hashmap_size"],
                                   moving_step=self.moving_step, use_div_offsets=self.use_div_offsets,
-                                  use_time_embedding=self.time_mode != 0, use_time_attenuation=self.time_mode == 2)
-            m.hash_table = self.hash_table
+                                  use_time_embedding=self.time_mode != 0, use_time_attenuation=self.time_mode == 2,
+                                  temporal_hash=self.temporal, hash_dtype=torch.float16 if self.table_f16 else torch.float32)
+            m.hash_table = torch.nn.Parameter(self.hash_table_half, requires_grad=False) if self.table_f16 else self.hash_table
             m.xyz_wrap, m.mlp_base, m.mlp_head = self.xyz_wrap, self.mlp_base, self.mlp_head
             m.aabb = self.aabb
             object.__setattr__(self, "_shared", m.eval())          # not a sub-module: the parameters are ours
@@ -434,6 +474,7 @@ def train_step(field: TrainableField, estimator, optimizer, rays_o: torch.Tensor
     if ts.shape[0] == 1:
         ts = ts.expand(n_rays, 1)
 
+    field.sync_half_table()                               # fp16-table fields: the evaluated copy follows the master
     fused = field.shared_inference()
 
     def sigma_fn(t_starts, t_ends, ray_indices):
@@ -476,4 +517,5 @@ def train_step(field: TrainableField, estimator, optimizer, rays_o: torch.Tensor
         grad_scaler.update()
     else:
         optimizer.step()
+    field.sync_half_table()
     return {"loss": float(loss.detach()), "n_samples": int(t_starts.shape[0])}

@@ -227,6 +227,14 @@ int ced_hash_encode(const ced_hash_desc *desc, int64_t n, const float *x, const 
 int ced_hash_encode_backward(const ced_hash_desc *desc, int64_t n, const float *x, const float *dy,
                              float *grad_table, float *dx, int32_t dx_scaled, void *stream);
 
+/* Backward of ced_hash_encode for TEMPORAL tables (desc->temporal: entry = 4 key-frames x 2 features), restating
+ * hash_encoder_backward_kernel of taichi_kernel/hash_encoder_inter.py:202-275: t [n] the sample times; grad_table
+ * [total_entries, 8] fp32 is ACCUMULATED into -- per corner the key-frames k and k + 1 of the sample's time receive
+ * w * dy * (1 - t_frac) and w * dy * t_frac (k, t_frac as in the forward, :228-240).  Like the reference's autograd
+ * function (:403-420) it yields the table gradient only: positions and times get none through this encoder. */
+int ced_hash_encode_backward_temporal(const ced_hash_desc *desc, int64_t n, const float *x, const float *t,
+                                      const float *dy, float *grad_table, void *stream);
+
 /* DNGPradianceField.forward(positions, t, directions) -- cednerf/model.py:468-488 (query_move
  * :354-365, query_density :367-445, _query_rgb :447-466), fused into one kernel.
  * dir/rgb may both be NULL (density only = query_density, model.py:367); geo [n,15] may be NULL

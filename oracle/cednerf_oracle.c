@@ -484,6 +484,51 @@ void ced_o_hash_encode_backward(const ced_o_hash_t *h, int64_t n, const float *x
     }
 }
 
+/* Backward of the TEMPORAL hash encode, hash_encoder_inter.py:202-275: table gradient only (the reference's autograd
+ * function gives positions none).  grad_table [E][8], accumulated in DOUBLE: per corner the key-frames k and k + 1 of
+ * the sample's time receive (w * dy) * (1 - t_frac) and (w * dy) * t_frac, k / t_frac as in the forward (:228-240). */
+void ced_o_hash_encode_backward_temporal(const ced_o_hash_t *h, int64_t n, const float *x_in, const float *t,
+                                         const float *dy, double *grad_table)
+{
+    for (int64_t i = 0; i < n; ++i) {
+        float x[3];
+        for (int a = 0; a < 3; ++a) x[a] = fminf(fmaxf(x_in[3 * i + a], 0.0f), 1.0f);
+        float ts = t[i] * 3.0f;
+        float fl = floorf(ts);
+        const float t_frac = ts - fl;
+        fl = fminf(fl, 2.0f);
+        const int k_lo = (int)fl;
+        for (int l = 0; l < h->n_levels; ++l) {
+            const float sc = h->scale[l];
+            const float g0 = dy[(i * h->n_levels + l) * 2], g1 = dy[(i * h->n_levels + l) * 2 + 1];
+            if (g0 == 0.0f && g1 == 0.0f) continue;                       /* grad_dy_temp.any(), :259 */
+            uint32_t g[3];
+            float fr[3], om[3];
+            for (int a = 0; a < 3; ++a) {
+                float pos = x[a] * sc + 0.5f;
+                float f = floorf(pos);
+                g[a] = (uint32_t)f;
+                fr[a] = pos - f;
+                om[a] = 1.0f - fr[a];
+            }
+            for (int c = 0; c < 8; ++c) {
+                float w = 1.0f;
+                uint32_t p[3];
+                for (int a = 0; a < 3; ++a) {
+                    if ((c & (1 << a)) == 0) { p[a] = g[a]; w = w * om[a]; }
+                    else { p[a] = g[a] + 1u; w = w * fr[a]; }
+                }
+                const size_t e = (size_t)h->offset[l] + grid_index(h, l, p[0], p[1], p[2]);
+                const float wg[2] = { w * g0, w * g1 };
+                for (int f = 0; f < 2; ++f) {
+                    grad_table[e * 8 + 2 * k_lo + f] += (double)(wg[f] * (1.0f - t_frac));
+                    grad_table[e * 8 + 2 * k_lo + 2 + f] += (double)(wg[f] * t_frac);
+                }
+            }
+        }
+    }
+}
+
 /* corner entry indices (into the table, offset included) of level l for a point: exposed so
  * tests can check the integer part of the lookup bit-exactly. */
 void ced_o_hash_indices(const ced_o_hash_t *h, int64_t n, const float *x_in, uint32_t *idx /* [n][L][8] */)

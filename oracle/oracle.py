@@ -200,6 +200,14 @@ class OracleField:
                                          C.c_int(int(dx_scaled)))
         return grad, dx
 
+    def hash_encode_backward_temporal(self, x: np.ndarray, t: np.ndarray, dy: np.ndarray) -> np.ndarray:
+        """hash_encoder_backward_kernel of the temporal table (hash_encoder_inter.py:202-275): grad_table [E,8] float64."""
+        x = _f32(x); dy = _f32(dy).reshape(x.shape[0], -1); t = _f32(t).reshape(-1)
+        assert self.p["hash"].get("temporal", False)
+        grad = np.zeros((self.levels["total"], 8), np.float64)
+        lib().ced_o_hash_encode_backward_temporal(C.byref(self.hash_t), C.c_int64(x.shape[0]), _p(x), _p(t), _p(dy), _p(grad))
+        return grad
+
     def hash_indices(self, x: np.ndarray) -> np.ndarray:
         x = _f32(x)
         n = x.shape[0]

@@ -185,6 +185,65 @@ def test_hash_encode_backward(oracle, max_res, log2T, dtype):
         assert abs(lhs - rhs) <= 2e-4 * max(abs(lhs), abs(rhs), 1.0), (lhs, rhs)
 
 
+@pytest.mark.parametrize("max_res,log2T,dtype", [(1024, 15, np.float32), (4096, 13, np.float16)])
+def test_hash_encode_backward_temporal(oracle, max_res, log2T, dtype):
+    """The temporal table's backward (hash_encoder_inter.py:202-275): per corner the key-frames k and k + 1 of the
+    sample's time receive w dy (1 - t_frac) and w dy t_frac -- against the oracle's double-precision sums, with t = 0, 1,
+    the key-frame times themselves and all-zero levels in the batch; duality with the forward (linear in the table)."""
+    from ced_nerf_amd import ops, synthetic as S
+    p = S.init_field_params([-1, -1, -1, 1, 1, 1], 1e-4, max_res, log2T, regime="trained", table_dtype=dtype,
+                            temporal_hash=True, use_time_embedding=True)
+    of = oracle.OracleField({"hash": p["hash"]})
+    n = 20000
+    x = _points(n, 8)[:n]
+    rng = np.random.default_rng(9)
+    t = rng.uniform(0, 1, size=n).astype(np.float32)
+    t[:8] = [0.0, 1.0, 1.0 / 3.0, 2.0 / 3.0, 0.999999, 0.3333333, 0.5, 0.6666667]
+    dy = rng.normal(size=(n, 32)).astype(np.float32)
+    dy[::7, 4:6] = 0.0
+    dy[3] = 0.0
+    want = of.hash_encode_backward_temporal(x, t, dy)
+    table = T(p["hash"]["table"])
+    assert table.shape[1] == 8
+    desc, _ = ops.make_hash_desc(table, 16, max_res, 16, log2T, True)
+    grad = ops.hash_encode_backward_temporal(desc, T(x), T(t), T(dy))
+    g = N(grad).astype(np.float64)
+    scale = np.abs(want).max()
+    assert scale > 1.0 and grad.shape == (table.shape[0], 8)
+    assert np.abs(g - want).max() <= 2e-5 * scale, np.abs(g - want).max() / scale
+    assert np.array_equal(g == 0, want == 0)                      # exactly the slots the oracle touches
+    grad2 = ops.hash_encode_backward_temporal(desc, T(x), T(t), T(dy), grad_table=grad.clone())
+    assert np.abs(N(grad2).astype(np.float64) - 2 * want).max() <= 4e-5 * scale
+    if dtype == np.float32:
+        dT = torch.randn_like(table) * 0.1
+        t2 = (table + dT).contiguous()
+        d2, _ = ops.make_hash_desc(t2, 16, max_res, 16, log2T, True)
+        lhs = ((ops.hash_encode(d2, T(x), T(t)) - ops.hash_encode(desc, T(x), T(t))).double() * T(dy).double()).sum().item()
+        rhs = (grad.double() * dT.double()).sum().item()
+        assert abs(lhs - rhs) <= 2e-4 * max(abs(lhs), abs(rhs), 1.0), (lhs, rhs)
+
+
+def test_temporal_hash_encoder_module():
+    """The reference-shaped temporal `HashEncoder` (hash_encoder_inter.py:281-430): xyzt in, [N, 32] out, a table gradient and
+    no position gradient; a few Adam steps fit a target that depends on time."""
+    from ced_nerf_amd.hashgrid import TemporalHashEncoder
+    torch.manual_seed(0)
+    enc = TemporalHashEncoder(max_params=2 ** 14, levels=16, base_res=16, max_res=256, device=DEV)
+    assert enc.n_output_dims == 32 and enc.hash_table.shape[1] == 8
+    xyzt = torch.rand(4096, 4, device=DEV, requires_grad=True)
+    target = torch.sin(xyzt.detach()[:, :3].sum(dim=1, keepdim=True) * 4.0 + xyzt.detach()[:, 3:] * 5.0).expand(-1, 32) * 0.1
+    opt = torch.optim.Adam(enc.parameters(), lr=1e-2)
+    losses = []
+    for _ in range(60):
+        opt.zero_grad()
+        loss = ((enc(xyzt) - target) ** 2).mean()
+        loss.backward()
+        opt.step()
+        losses.append(loss.item())
+    assert losses[-1] < 0.3 * losses[0], losses[::10]
+    assert xyzt.grad is None                                       # the reference's temporal encoder gives inputs no gradient
+
+
 def test_trainable_hash_encoder_module(oracle):
     """The reference-shaped `HashEncoder` module (hash_encoder_half.py:231-385) on the HIP kernels: a few SGD steps on
     a regression target reduce the loss, and autograd's gradients are the kernels' gradients."""
@@ -2284,6 +2343,85 @@ def test_fused_mlp_chain_equals_layerwise(oracle, widths, n):
     assert torch.equal(one[0], ref[0]) and torch.equal(one[1], ref[1])          # the same walk: the same input gradient
     for a, b in zip(one[2], ref[2]):
         assert (a - b).abs().max().item() <= 2e-5 * b.abs().max().item() + 1e-30
+
+
+@pytest.mark.parametrize("kind", ["f16_table", "temporal", "temporal_f16"])
+def test_training_on_the_reference_table_types(oracle, kind):
+    """train_real.py trains fp16 tiny-cuda-nn parameters under autocast (:330; fp32 master, fp16 evaluated copy) and the
+    temporal table has a backward of its own (hash_encoder_inter.py:202-275).  TrainableField on those table types: the
+    differentiable forward equals the fused inference kernel on the same parameters (which reads the fp16 / temporal table
+    natively), the table gradient of a loss equals the oracle's float64 gradient of the same encode, and a student with a
+    damaged table relearns a teacher's renders (the evaluated fp16 copy following its fp32 master step by step)."""
+    from ced_nerf_amd import ops, synthetic as S
+    from ced_nerf_amd.nerfacc_api import OccGridEstimator
+    from ced_nerf_amd.train import TrainableField, train_step
+    from ced_nerf_amd.utils import Rays, render_image
+    temporal, f16 = kind.startswith("temporal"), kind.endswith("f16") or kind == "f16_table"
+    kw = dict(table_dtype=np.float16 if f16 else np.float32)
+    if temporal:
+        kw.update(temporal_hash=True, use_time_embedding=True)
+    cfg = S.CONFIGS["dnerf"]
+    params = S.init_field_params(cfg["aabb"], cfg["moving_step"], cfg["hash_max_res"], 14, regime="trained", seed=3, **kw)
+    tf = TrainableField(params, DEV)
+    assert tf.temporal == temporal and tf.table_f16 == f16 and tf.hash_table.dtype == torch.float32
+    assert tf.hash_table.shape[1] == (8 if temporal else 2)
+    f = tf.to_inference(DEV)
+    assert f.hash_table.dtype == (torch.float16 if f16 else torch.float32)
+    rng = np.random.default_rng(5)
+    n = 6000
+    pos = rng.uniform(-1.6, 1.6, size=(n, 3)).astype(np.float32)
+    t = rng.uniform(0, 1, size=(n, 1)).astype(np.float32)
+    d = rng.normal(size=(n, 3)).astype(np.float32)
+    rgb_t, sig_t = tf(T(pos), T(t), T(d))
+    rgb_f, res = f(T(pos), T(t), T(d))
+    assert (rgb_t - rgb_f).abs().max().item() <= 5e-5
+    sig_f = res["density"][:, 0]
+    assert torch.equal(sig_t == 0, sig_f == 0)
+    assert ((sig_t - sig_f).abs() <= 2e-4 * sig_f.abs() + 1e-12).all()
+    # the table gradient through autograd == the oracle's float64 gradient of the encode for the same upstream gradient
+    tf.zero_grad(set_to_none=True)
+    xn = torch.rand(3000, 3, device=DEV)
+    tt = torch.rand(3000, device=DEV)
+    from ced_nerf_amd.train import _HashFn
+    up = torch.randn(3000, 32, device=DEV)
+    feats = _HashFn.apply(xn, tf.hash_table, tf.hash_cfg, tt, tf._table_eval())
+    (feats * up).sum().backward()
+    of = oracle.OracleField({"hash": dict(params["hash"])})
+    if temporal:
+        want = of.hash_encode_backward_temporal(N(xn), N(tt), N(up))
+    else:
+        want, _ = of.hash_encode_backward(N(xn), N(up))
+    got = N(tf.hash_table.grad).astype(np.float64)
+    assert got.shape == want.shape and np.abs(got - want).max() <= 2e-5 * np.abs(want).max()
+    # a short training run: teacher = these parameters, student = a damaged table
+    sc = _scene("dnerf", 64, 48, "trained", log2_hashmap_size=14)
+    est = OccGridEstimator(cfg["aabb"], cfg["grid_resolution"], cfg["grid_levels"]).to(DEV)
+    est.set_binaries(T(sc["binaries"]))
+    bk = T(sc["render"]["render_bkgd"])
+    rk = dict(sc["render"], render_bkgd=bk)
+    rays = Rays(T(sc["origins"]), T(sc["viewdirs"]))
+    ts = T(sc["timestamps"])
+    target = render_image(f, est, rays, timestamps=ts, **rk)[0].reshape(-1, 3)
+    sp = dict(params); sp["hash"] = dict(params["hash"])
+    tab = params["hash"]["table"].astype(np.float32)
+    sp["hash"]["table"] = (tab * 0.5 + rng.normal(size=tab.shape) * 0.05).astype(params["hash"]["table"].dtype)
+    student = TrainableField(sp, DEV)
+    opt = torch.optim.Adam([student.hash_table], lr=2e-2)
+    o = rays.origins.reshape(-1, 3); dd = rays.viewdirs.reshape(-1, 3)
+    idx_all = ((target - bk).abs().sum(dim=1) > 1e-3).nonzero().flatten()
+    assert idx_all.numel() > 200
+    g = torch.Generator(device=DEV).manual_seed(1)
+    losses = []
+    for step in range(30):
+        idx = idx_all[torch.randint(0, idx_all.numel(), (1024,), device=DEV, generator=g)]
+        out = train_step(student, est, opt, o[idx].contiguous(), dd[idx].contiguous(), ts, target[idx].contiguous(),
+                         cfg["render_step_size"], near_plane=cfg["near_plane"], far_plane=cfg["far_plane"], render_bkgd=bk)
+        assert out["n_samples"] > 0 and np.isfinite(out["loss"])
+        losses.append(out["loss"])
+    print(kind, "losses", [round(x, 5) for x in losses[::5]])
+    assert np.mean(losses[-5:]) < 0.7 * np.mean(losses[:5]), losses
+    if f16:       # the evaluated copy is the master rounded to fp16, after every step
+        assert torch.equal(student.hash_table_half, student.hash_table.detach().half())
 
 
 def test_training_steps_reduce_the_loss(oracle):
