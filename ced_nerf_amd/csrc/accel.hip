@@ -7,7 +7,7 @@
 #include <vector>
 
 #include "ced_common.hpp"
-#include "march_sm.hpp"
+#include "march_accel.hpp"
 
 namespace ced {
 
@@ -331,12 +331,10 @@ extern "C" int ced_host_march_frame(int64_t n_rays, const float *rays_o, const f
         const uint8_t *hr = hits + r * n_grids;
         // the kernels' instantiations: one grid level recomputes the ray/box interval, LOOK = 4 cells
         if (n_grids == 1)
-            counts[r] = start_coarse == 3 ? ced::sm_run_ray<true>(G, S, o, d, near_planes[r], far_plane, ts, ti, hr, emit, t_term[r])
-                      : start_coarse == 1 ? ced::traverse_ray_frame<ced::kFrameLook, true, true>(G, S, true, o, d, near_planes[r], far_plane, ts, ti, hr, emit, t_term[r])
-                                        : ced::traverse_ray_frame<ced::kFrameLook, true, false>(G, S, start_coarse != 0, o, d, near_planes[r], far_plane, ts, ti, hr, emit, t_term[r]);
+            counts[r] = start_coarse == 1 ? ced::traverse_ray_frame<ced::kFrameLook, true, true>(G, S, true, o, d, near_planes[r], far_plane, ts, ti, hr, emit, t_term[r])
+                                          : ced::traverse_ray_frame<ced::kFrameLook, true, false>(G, S, start_coarse != 0, o, d, near_planes[r], far_plane, ts, ti, hr, emit, t_term[r]);
         else
-            counts[r] = start_coarse == 3 ? ced::sm_run_ray<false>(G, S, o, d, near_planes[r], far_plane, ts, ti, hr, emit, t_term[r])
-                      : start_coarse == 1 ? ced::traverse_ray_frame<ced::kFrameLook, false, true>(G, S, true, o, d, near_planes[r], far_plane, ts, ti, hr, emit, t_term[r])
+            counts[r] = start_coarse == 1 ? ced::traverse_ray_frame<ced::kFrameLook, false, true>(G, S, true, o, d, near_planes[r], far_plane, ts, ti, hr, emit, t_term[r])
                                         : ced::traverse_ray_frame<ced::kFrameLook, false, false>(G, S, start_coarse != 0, o, d, near_planes[r], far_plane, ts, ti, hr, emit, t_term[r]);
     }
     return CED_OK;

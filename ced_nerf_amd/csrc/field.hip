@@ -338,7 +338,6 @@ __global__ __launch_bounds__(256) void hash_backward_kernel(HashBwdArgs A)
 std::atomic<int> g_field_stagger{ 0 };          // field kernel: start-up phase offset between the waves of a SIMD, in s_sleep(127) units
 std::atomic<int> g_field_spread_tiles{ 1 };     // field kernels: deal tiles across all CUs first
 std::atomic<int> g_march_early_out{ 1 };        // frame renderer: conservative brick-level early-out
-std::atomic<int> g_march_sm{ 0 };               // frame renderer: candidate list on persistent waves with lane-level ray fetch
 std::atomic<int> g_march_two_pass{ -1 };        // frame renderer: first iteration as culling pass + marching of the rest (-1: when there are several grid levels)
 
 // launch-geometry variant of the field kernel (ced_set_option("field_variant", v))
@@ -465,10 +464,6 @@ extern "C" int ced_set_option(const char *key, int value)
     }
     if (strcmp(key, "march_early_out") == 0) {
         ced::g_march_early_out = value != 0;
-        return CED_OK;
-    }
-    if (strcmp(key, "march_sm") == 0) {
-        ced::g_march_sm = value != 0;
         return CED_OK;
     }
     if (strcmp(key, "march_two_pass") == 0) {

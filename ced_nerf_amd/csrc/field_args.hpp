@@ -37,7 +37,6 @@ struct FieldArgs {
 
 extern std::atomic<int> g_march_early_out;
 extern std::atomic<int> g_march_two_pass;
-extern std::atomic<int> g_march_sm;
 extern std::atomic<int> g_field_spread_tiles;
 constexpr int kFieldBlocksDefault = 256;      // one persistent workgroup per CU
 

@@ -25,6 +25,7 @@
 
 #include "ced_common.hpp"
 #include "field_args.hpp"
+#include "march_accel.hpp"
 
 #ifdef CED_MARCH_DIAG
 // [phase][0] passes of a wave through the phase, [1] lanes active in those passes, [2] cycles of the wave between this
@@ -79,7 +80,6 @@ __device__ void ced_diag_flush()
     }
 }
 #endif
-#include "march_sm.hpp"
 
 namespace ced {
 
@@ -561,157 +561,6 @@ extern "C" int ced_diag_march_waves(unsigned int *out, int max_rows, int reset)
 }
 namespace ced {
 #endif
-
-// The candidate list on PERSISTENT waves with lane-level ray fetch (march_sm.hpp): a wave keeps 64
-// rays in flight, each in its own phase of the walk; every trip of the loop steps each phase that has lanes in it, and
-// lanes whose ray is finished are flushed (one range reservation per wave and flush) and take the next rays of the list
-// from a device-side cursor.  Only as many waves take part as give every lane kSmRaysPerLane rays on average -- with one
-// ray per lane there is nothing to refill with.  Exit: the cursor only grows and a lane past the end of the list is
-// DONE for good, so every wave leaves after its last ray (plus a trip guard).
-#ifndef CED_SM_RAYS_PER_LANE
-#define CED_SM_RAYS_PER_LANE 2
-#endif
-#ifndef CED_SM_REFILL
-#define CED_SM_REFILL 16
-#endif
-constexpr int kSmRaysPerLane = CED_SM_RAYS_PER_LANE;
-constexpr int kSmRefill = CED_SM_REFILL;             // lanes without a ray that trigger a flush + fetch
-template <bool SINGLE>
-__global__ __launch_bounds__(kMarchThreads, 2) void march_cand_sm_kernel(MarchArgs A, IterPlan *__restrict__ plan)
-{
-    const IterPlan &P = *plan;
-    const int total = P.n_cand;
-    const int lane = threadIdx.x & 63;
-    const int wave_id = blockIdx.x * (kMarchThreads / 64) + (threadIdx.x >> 6);
-    const int n_waves = gridDim.x * (kMarchThreads / 64);
-    int take_part = (total + 64 * kSmRaysPerLane - 1) / (64 * kSmRaysPerLane);
-    if (take_part > n_waves) take_part = n_waves;
-    if (wave_id >= take_part) return;
-    const GridSpec grid = A.grid;
-    const int m = grid.n_grids;
-    RaySM s{};
-    s.phase = SM_IDLE;
-    s.limit = 1;
-    int64_t r = 0;
-    float run_t[kMaxRuns], prev_end = 0.0f;
-    int run_n[kMaxRuns], n_runs = 0;
-#pragma unroll
-    for (int k = 0; k < kMaxRuns; ++k) { run_t[k] = 0.0f; run_n[k] = 0; }
-    // a ray whose samples do not fit the run slots (or a walk without a step size) goes through the machine a second
-    // time after its reservation, storing directly
-    bool rewalk = false;
-    int64_t rewalk_start = 0;
-    auto note = [&](int i, float t0, float t1) {
-        if (rewalk) {
-            A.t_starts[rewalk_start + i] = t0; A.t_ends[rewalk_start + i] = t1; A.ray_idx[rewalk_start + i] = (int32_t)r;
-            return;
-        }
-        const bool fresh = i == 0 || t0 != prev_end;
-        if (fresh) ++n_runs;
-        prev_end = t1;
-#pragma unroll
-        for (int k = 0; k < kMaxRuns; ++k) {
-            const bool here = n_runs == k + 1;
-            run_t[k] = (here && fresh) ? t0 : run_t[k];
-            run_n[k] += here ? 1 : 0;
-        }
-    };
-    for (int trip = 0; trip < (1 << 18); ++trip) {          // (a wave needs a few hundred trips; the bound only ends a runaway)
-        const unsigned long long fin = __ballot(s.phase == SM_FIN);
-        const unsigned long long idle = __ballot(s.phase == SM_IDLE);
-        const unsigned long long busy = __ballot(s.phase != SM_FIN && s.phase != SM_IDLE && s.phase != SM_DONE);
-        if ((fin | idle) != 0 && (__builtin_popcountll(fin | idle) >= kSmRefill || busy == 0)) {
-            if (fin != 0) {
-                // flush: one reservation for the wave's finished rays, samples regenerated from the runs
-                const int cnt = (s.phase == SM_FIN && !rewalk) ? s.n : 0;
-                int incl = cnt;
-#pragma unroll
-                for (int off = 1; off < 64; off <<= 1) {
-                    const int v = __shfl_up(incl, off, 64);
-                    if (lane >= off) incl += v;
-                }
-                const int wave_total = __shfl(incl, 63, 64);
-                unsigned long long base = 0;
-                if (lane == 0 && wave_total > 0)
-                    base = atomicAdd(reinterpret_cast<unsigned long long *>(&plan->total_samples), (unsigned long long)wave_total);
-                base = __shfl((unsigned long long)base, 0, 64);
-                if (s.phase == SM_FIN && rewalk) {            // the second walk has stored the samples
-                    rewalk = false;
-                    s.phase = SM_IDLE;
-                } else if (s.phase == SM_FIN) {
-                    const int64_t start = (int64_t)base + incl - cnt;
-                    const int n = s.n;
-                    A.packed[2 * r] = (int32_t)start;
-                    A.packed[2 * r + 1] = n;
-                    A.near_planes[r] = s.t_term;
-                    if (n > 0 && (n_runs > kMaxRuns || !(grid.step_size > 0.0f))) {
-                        rewalk = true;
-                        rewalk_start = start;
-                        const float o[3] = { s.o[0], s.o[1], s.o[2] }, d[3] = { s.d[0], s.d[1], s.d[2] };
-                        sm_begin(s, o, d, s.near, s.far, s.limit);
-                    } else {
-                        float *const p0 = A.t_starts + start, *const p1 = A.t_ends + start;
-                        int32_t *const pr = A.ray_idx + start;
-                        int pos = 0;
-#pragma unroll
-                        for (int k = 0; k < kMaxRuns; ++k) {
-                            float t = run_t[k];
-                            for (int j = 0; j < run_n[k]; ++j) {
-                                const float t1 = t + calc_dt(t, grid.cone_angle, grid.step_size, 1e10f);
-                                p0[pos] = t; p1[pos] = t1; pr[pos] = (int32_t)r;
-                                ++pos;
-                                t = t1;
-                            }
-                        }
-                        s.phase = SM_IDLE;
-                    }
-                }
-            }
-            // fetch: the idle lanes take the next entries of the list
-            const bool want = s.phase == SM_IDLE;
-            const unsigned long long wmask = __ballot(want);
-            const int k = __builtin_popcountll(wmask);
-            int first = 0;
-            if (lane == 0 && k > 0) first = atomicAdd(&plan->cursor, k);
-            first = __shfl(first, 0, 64);
-            if (want) {
-                const int idx = first + __builtin_popcountll(wmask & ((1ull << lane) - 1ull));
-                if (idx < total && first >= 0) {
-                    r = A.cand[idx];
-                    const int f = (int)(r / A.rays_per_frame);
-                    float o[3], d[3];
-#pragma unroll
-                    for (int a = 0; a < 3; ++a) { o[a] = A.rays_o[3 * r + a]; d[a] = A.rays_d[3 * r + a]; }
-                    sm_begin(s, o, d, A.near_planes[r], A.far_plane, P.limit[f]);
-                    n_runs = 0; prev_end = 0.0f;
-#pragma unroll
-                    for (int q = 0; q < kMaxRuns; ++q) { run_t[q] = 0.0f; run_n[q] = 0; }
-                } else {
-                    s.phase = SM_DONE;
-                }
-            }
-        }
-        if (__ballot(s.phase != SM_DONE) == 0) break;
-        // one step of every phase that has lanes in it, in the order a ray goes through them
-        GridSpec gl = grid;
-        if (s.phase == SM_SEG)
-            sm_seg<SINGLE>(s, gl, SINGLE ? nullptr : A.t_sorted + r * 2 * m,
-                           SINGLE ? (const uint8_t *)nullptr : A.t_indices + r * 2 * m, SINGLE ? nullptr : A.hits + r * m);
-#pragma unroll 1
-        for (int k = 0; k < 4; ++k) {
-            if (s.phase == SM_TRACE) sm_probe(s, gl, A.accel);
-            if (__builtin_popcountll(__ballot(s.phase == SM_TRACE)) < 32) break;
-        }
-        if (s.phase == SM_SETUP) sm_setup(s, gl);
-        if (s.phase == SM_REENTER) sm_reenter(s);
-#pragma unroll 1
-        for (int k = 0; k < 4; ++k) {
-            if (s.phase == SM_WALK) sm_walk(s, gl, A.accel);
-            if (__builtin_popcountll(__ballot(s.phase == SM_WALK)) < 32) break;
-        }
-        if (s.phase == SM_EMIT) sm_emit(s, gl, note);
-    }
-}
 
 // composite_prefix (cednerf/utils.py:274-299) + ray bookkeeping (utils.py:301-307) over the list of alive rays;
 // survivors (opacity <= threshold and a full sample budget) are appended to the next iteration's list, one range
@@ -1456,16 +1305,12 @@ static int render_frames_impl(const ced_field_desc *field, int n_frames, int64_t
             int64_t kgrid = (slot_bound + kCullThreads - 1) / kCullThreads;
             if (kgrid > 8192) kgrid = 8192;
             if (mgrid > 4096) mgrid = 4096;                  // the list's length is only known on the device
-            const bool sm = g_march_sm != 0;                 // the list on persistent waves with lane-level ray fetch
-            constexpr unsigned kSmGrid = 256 * 2 * 4 / (kMarchThreads / 64);       // every wave slot of the chip at 2 per SIMD
             if (n_grids == 1) {
                 hipLaunchKernelGGL(march_cull_kernel<true>, dim3((unsigned)kgrid), dim3(kCullThreads), 0, stream, M, plan);
-                if (sm) hipLaunchKernelGGL(march_cand_sm_kernel<true>, dim3(kSmGrid), mblk, 0, stream, M, plan);
-                else hipLaunchKernelGGL((march_frame_kernel<true, true, true>), dim3((unsigned)mgrid), mblk, 0, stream, M, plan);
+                hipLaunchKernelGGL((march_frame_kernel<true, true, true>), dim3((unsigned)mgrid), mblk, 0, stream, M, plan);
             } else {
                 hipLaunchKernelGGL(march_cull_kernel<false>, dim3((unsigned)kgrid), dim3(kCullThreads), 0, stream, M, plan);
-                if (sm) hipLaunchKernelGGL(march_cand_sm_kernel<false>, dim3(kSmGrid), mblk, 0, stream, M, plan);
-                else hipLaunchKernelGGL((march_frame_kernel<false, true, true>), dim3((unsigned)mgrid), mblk, 0, stream, M, plan);
+                hipLaunchKernelGGL((march_frame_kernel<false, true, true>), dim3((unsigned)mgrid), mblk, 0, stream, M, plan);
             }
         } else if (it == 0) {
             if (n_grids == 1) hipLaunchKernelGGL((march_frame_kernel<true, false, true>), dim3((unsigned)mgrid), mblk, 0, stream, M, plan);

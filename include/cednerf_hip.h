@@ -85,9 +85,9 @@ const char *ced_last_error_string(void);
  * "march_early_out": 1 (default) lets the frame renderer's marching cross empty space through the brick distance
  * field, 0 walks every cell;
  * "march_two_pass": the frame renderer's first iteration as a culling pass (the sphere trace alone, every ray) and a
- * marching pass over the rays it could not rule out: 1 / 0, -1 (default) = when there are several grid levels;
- * "march_sm": 1 = that marching pass on persistent waves whose lanes take the next ray of the list when theirs is done
- * (csrc/march_sm.hpp: the walk as a resumable state machine), 0 (default: measured 3x slower than the full-wave pass). */
+ * marching pass over the rays it could not rule out: 1 / 0, -1 (default) = when there are several grid levels.
+ * (Round 3's "march_sm" -- that pass on persistent waves with lane-level ray fetch -- was bit-exact and 3x slower; removed
+ * in round 4, HISTORY 4.2 keeps the measurements.) */
 int ced_set_option(const char *key, int value);
 
 /* Arithmetic of xyz_wrap / mlp_base / mlp_head (everything else is fp32 in every mode):
@@ -193,8 +193,7 @@ int ced_build_occupancy_accel(const uint8_t *binaries, int32_t n_grids, int32_t 
  * binade, as in a frame with cone_angle == 0 (every near plane must then be a point of the lattice t_0 = near_planes[0],
  * t_{k+1} = t_k + step: the frame's near plane or an earlier termination plane).  start_coarse: 0 = the walk of a
  * frame's later iterations (no trace at a segment's start, emission inline), 1 = a frame's first iteration (trace
- * first, looking loop + emission phase), 2 = the one-shot march (trace first, emission inline), 3 = form 1 as the
- * resumable state machine the candidate-list kernel steps (march_sm.hpp; needs accel_mode >= 1).  All pointers are
+ * first, looking loop + emission phase), 2 = the one-shot march (trace first, emission inline).  All pointers are
  * host pointers. */
 int ced_host_build_occupancy_accel(const uint8_t *binaries_host, int32_t n_grids, int32_t res, uint8_t *accel_host);
 int32_t ced_host_count_steps(float *x, float d, float tau, int32_t kcap, float *prev);

@@ -1287,9 +1287,8 @@ def test_sort_intersections_is_torch_stable_sort(oracle, m):
 
 @pytest.mark.parametrize("name", ["dnerf", "hypernerf", "dynerf"])
 def test_first_iteration_forms_give_the_same_frames(oracle, name):
-    """The first marching iteration has three forms -- one pass; culling pass + candidate list; the candidate list on
-    persistent waves with lane-level ray fetch (march_sm.hpp, off by default: measured slower) -- selected by
-    ced_set_option.  Every form renders the same frames bit for bit (several frames per call, a frame that sees nothing,
+    """The first marching iteration has two forms -- one pass; culling pass + candidate list -- selected by
+    ced_set_option.  Both render the same frames bit for bit (several frames per call, a frame that sees nothing,
     a sample budget that ends the loop early)."""
     from ced_nerf_amd import _lib, synthetic as S
     from ced_nerf_amd.model import DNGPradianceField
@@ -1314,17 +1313,17 @@ def test_first_iteration_forms_give_the_same_frames(oracle, name):
     L = _lib.lib()
     outs = {}
     try:
-        for form, (two, sm) in {"one pass": (0, 0), "cull + list": (1, 0), "cull + lane fetch": (1, 1)}.items():
-            assert L.ced_set_option(b"march_two_pass", two) == 0 and L.ced_set_option(b"march_sm", sm) == 0
+        for form, two in {"one pass": 0, "cull + list": 1}.items():
+            assert L.ced_set_option(b"march_two_pass", two) == 0
             for ms in (1024, 24):
                 outs[(form, ms)] = render_frames_test(ms, f, est, rays, timestamps=ts, **rk)
                 torch.cuda.synchronize()
     finally:
-        L.ced_set_option(b"march_two_pass", -1); L.ced_set_option(b"march_sm", 0)
+        L.ced_set_option(b"march_two_pass", -1)
     for ms in (1024, 24):
         ref = outs[("one pass", ms)]
         assert sum(ref[3]) > 20000 and ref[3][2] == 0
-        for form in ("cull + list", "cull + lane fetch"):
+        for form in ("cull + list",):
             got = outs[(form, ms)]
             assert list(got[3]) == list(ref[3]), (form, ms, got[3], ref[3])
             assert torch.equal(got[0], ref[0]) and torch.equal(got[1], ref[1]) and torch.equal(got[2], ref[2]), (form, ms)

@@ -149,7 +149,7 @@ def test_march_frame_matches_oracle_on_the_dataset_shaped_scenes(hip, oracle, na
             near = np.full((n,), sc["render"]["near_plane"], np.float32)
             if resume:       # later iterations: every ray resumes at its own termination plane
                 near = (near + rng.uniform(0, 6, size=n)).astype(np.float32)
-            for start_coarse in (1, 0, 2, 3):  # first iteration / later iterations / one-shot march / state machine
+            for start_coarse in (1, 0, 2):  # first iteration / later iterations / one-shot march
                 for mode in (2, 1):          # brick + cell fields (a caller's accel); brick field only (built per call)
                     s, full, dist = _march_case(hip, oracle, sc, limit, near, start_coarse, accel_mode=mode)
                     total += s
