@@ -777,20 +777,39 @@ static void dense_half_cached(const half_layer_t *L, const float *x_in, float *y
             (void)mfma_f16_decompose(p[h], &xe[h][i], &xm[h][i]);
         }
     }
+    /* per block, the inputs that are not zero (half of a ReLU layer's activations are): shared by every output row */
+    int8_t cnt_c[48];
+    int16_t in_c[48][8];
+    int16_t xe_c[48][8];
+    int32_t xm_c[48][8];
+    for (int b = 0; b < L->n_blocks; ++b) {
+        const half_block_t *B = &L->blocks[b];
+        const int xh = B->term == 1 ? 1 : 0;
+        int c = 0;
+        for (int q = 0; q < B->cnt; ++q) {
+            const int in = B->in[q];
+            if (xm[xh][in] == 0) continue;
+            in_c[b][c] = (int16_t)in; xe_c[b][c] = (int16_t)xe[xh][in]; xm_c[b][c] = xm[xh][in];
+            ++c;
+        }
+        cnt_c[b] = (int8_t)c;
+    }
     for (int o = 0; o < L->n_out; ++o) {
         const int64_t row = (int64_t)o * L->n_in;
         float acc = 0.0f;
         for (int b = 0; b < L->n_blocks; ++b) {
-            const half_block_t *B = &L->blocks[b];
-            const int wh = B->term == 0 ? 1 : 0, xh = B->term == 1 ? 1 : 0;      /* 0: w_lo*x_hi  1: w_hi*x_lo  2: w_hi*x_hi */
+            const int c = cnt_c[b];
+            if (c == 0) continue;                                         /* a block of zero products leaves acc as it is */
+            const int wh = L->blocks[b].term == 0 ? 1 : 0;                /* 0: w_lo*x_hi  1: w_hi*x_lo  2: w_hi*x_hi */
+            const int16_t *we = L->we[wh] + row, *wm = L->wm[wh] + row;
             int e[8];
             int32_t m[8];
-            for (int q = 0; q < B->cnt; ++q) {
-                const int in = B->in[q];
-                e[q] = L->we[wh][row + in] + xe[xh][in];
-                m[q] = (int32_t)L->wm[wh][row + in] * xm[xh][in];
+            for (int q = 0; q < c; ++q) {
+                const int in = in_c[b][q];
+                e[q] = we[in] + xe_c[b][q];
+                m[q] = (int32_t)wm[in] * xm_c[b][q];
             }
-            acc = mfma_f16_block_em(acc, B->cnt, e, m);
+            acc = mfma_f16_block_em(acc, c, e, m);
         }
         y[o] = relu ? (acc > 0.0f ? acc : 0.0f) : acc;
     }

@@ -1582,7 +1582,7 @@ def test_gui_operating_point(oracle, prec, regime):
     `max_samples`, not on dead rays: schedule, totals and every pixel against the oracle's mode of the same name, bit for bit."""
     from ced_nerf_amd import cameras, ops
     from ced_nerf_amd.utils import render_image_test
-    W, H = 160, 120
+    W, H = 128, 96
     sc = _scene("dnerf", W, H, regime, log2_hashmap_size=17)
     of, oest, f, est, rays, rk = _setup(oracle, sc)
     cfg = sc["cfg"]
@@ -1595,7 +1595,7 @@ def test_gui_operating_point(oracle, prec, regime):
     ts = torch.tensor([[0.0]], device=DEV)                      # gui.py:200: the viewer starts at t = 0
     ofm = oracle.OracleField(sc["params"], mlp_half=prec)
     totals = {}
-    for max_samples in (200, 1024):
+    for max_samples in (200, 1024) if regime == "trained" else (200, 320):       # (init: 320 keeps the oracle's share short)
         trace = []
         want = oracle.render_image_test(max_samples, ofm, oest, o_np, d_np, timestamps=N(ts), trace=trace, **sc["render"])
         tracer = ops.FrameTracer(capacity=1100, with_events=False)
@@ -1606,7 +1606,7 @@ def test_gui_operating_point(oracle, prec, regime):
             assert_bitexact(N(g_), w_, f"gui frame {prec} max_samples={max_samples} {nm}")
         totals[max_samples] = (got[3], sum(t["n_samples"] for t in trace))
     # random-init field: at 200 the loop ends on the budget (cednerf/utils.py:230) with rays still alive
-    assert totals[200][1] >= 200 and (regime != "init" or totals[200][0] < totals[1024][0]), totals
+    assert totals[200][1] >= 200 and (regime != "init" or totals[200][0] < totals[320][0]), totals
 
 
 def S_look_at(cfg):
@@ -1921,7 +1921,7 @@ def test_bench_two_rank_rehearsal():
 def test_bench_two_rank_rehearsal_weak_scaling():
     """The same launch line with --scaling weak: per-GPU work fixed (a call holds frames_per_call x ranks frames, a
     unit = one rank's share of ONE frame), the strong figure beside it."""
-    d = _two_rank_bench(["--also", "", "--scaling", "weak"])
+    d = _two_rank_bench(["--also", "", "--scaling", "weak", "--no-single-frame"])
     assert d["n_gpus"] == 2 and d["scaling"] == "weak" and d["config"]["frames_per_step"] == 18
     assert d["config"]["frames_per_call"] == 6 and d["other_scaling"]["scaling"] == "strong"
     _assert_gather_is_the_single_rank_render(d["gather_check"], 3)
