@@ -34,19 +34,31 @@ constexpr float kHalfMax = 65504.0f;
 // hence every sample count, opacity and depth -- and rgb.  (Rounds 1-3 used the hardware's 1-ulp exp2 / reciprocal /
 // rsqrt here: 2-3 % faster, not reproducible on a CPU.)
 
-// eight fp32 values -> packed fp16 operand (and the fp16 remainder in F16X2 mode)
+// eight fp32 values -> packed fp16 operand (and the fp16 remainder in F16X2 mode).  Two values at a time: ONE packed
+// conversion gives both high parts (v_cvt_pk_f16_f32, round to nearest even like the scalar form), which are widened
+// back for the remainders straight out of the packed register -- the scalar formulation converted every value twice
+// (once alone for the remainder, once more for the pack): 5 vector instructions per value instead of 4.
+typedef _Float16 h2 __attribute__((ext_vector_type(2)));
+typedef float f2v __attribute__((ext_vector_type(2)));
 template <bool SPLIT> __device__ __forceinline__ void to_half8(const float (&v)[8], h8 &hi, h8 &lo)
 {
 #pragma unroll
-    for (int e = 0; e < 8; ++e) {
-        // The value is made opaque first: left visible, hipcc folds a producing multiply / fma into the conversion
+    for (int e = 0; e < 8; e += 2) {
+        // The values are made opaque first: left visible, hipcc folds a producing multiply / fma into the conversion
         // (v_fma_mixlo_f16), which rounds ONCE to fp16 instead of to fp32 and then to fp16 -- a different result
         // whenever the fp32 value is an fp16 tie (found in round 4: the SH inputs of the f16 kernels, 1 value in 8192).
-        float x = v[e];
-        asm("" : "+v"(x));
-        const _Float16 h = (_Float16)x;
-        hi[e] = h;
-        if constexpr (SPLIT) lo[e] = (_Float16)(x - (float)h);
+        float x0 = v[e], x1 = v[e + 1];
+        asm("" : "+v"(x0));
+        asm("" : "+v"(x1));
+        const h2 h = __builtin_convertvector(f2v{ x0, x1 }, h2);
+        hi[e] = h[0];
+        hi[e + 1] = h[1];
+        if constexpr (SPLIT) {
+            const f2v back = __builtin_convertvector(h, f2v);
+            const h2 l = __builtin_convertvector(f2v{ x0, x1 } - back, h2);       // exact differences, one packed subtract
+            lo[e] = l[0];
+            lo[e + 1] = l[1];
+        }
     }
 }
 
