@@ -15,6 +15,7 @@ typedef _Float16 h8 __attribute__((ext_vector_type(8)));
 typedef _Float16 h4 __attribute__((ext_vector_type(4)));
 typedef float f4 __attribute__((ext_vector_type(4)));
 typedef float f2 __attribute__((ext_vector_type(2)));
+typedef float f16v __attribute__((ext_vector_type(16)));
 
 __device__ __forceinline__ f2 pk_op(int mode, f2 a, f2 b, f2 &want)
 {
@@ -93,13 +94,21 @@ __global__ __launch_bounds__(768) void probe(int mfma_mode, int pk_mode, int ite
         f4 first[4];
         for (int it = 0; it < iters; ++it) {
             f4 acc[4];
-            for (int j = 0; j < 4; ++j) acc[j] = f4{ 0.0f, 0.0f, 0.0f, 0.0f };
+            f16v acc32[4];
+            for (int j = 0; j < 4; ++j) {
+                acc[j] = f4{ 0.0f, 0.0f, 0.0f, 0.0f };
+                for (int r = 0; r < 16; ++r) acc32[j][r] = 0.0f;
+            }
 #pragma unroll
             for (int rep = 0; rep < 4; ++rep) {
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
                     if (mfma_mode == 1) {
                         acc[j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b[j], acc[j], 0, 0, 0);
+                    } else if (mfma_mode == 3) {
+                        // the other full-rate fp16 form of gfx950 (round 4): 32x32x16, 16 accumulator registers
+                        acc32[j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b[j], acc32[j], 0, 0, 0);
+                        acc[j] = f4{ acc32[j][0], acc32[j][5], acc32[j][10], acc32[j][15] };
                     } else {
                         const h4 a0 = { a[0], a[1], a[2], a[3] }, a1 = { a[4], a[5], a[6], a[7] };
                         const h4 b0 = { b[j][0], b[j][1], b[j][2], b[j][3] }, b1 = { b[j][4], b[j][5], b[j][6], b[j][7] };
@@ -148,13 +157,13 @@ int main(int argc, char **argv)
     float *example;
     hipMalloc(&example, 64);
     hipMalloc(&sink, 256 * 768 * sizeof(float));
-    const char *mf[] = { "no MFMA", "16x16x32_f16", "2 x 16x16x16_f16" };
+    const char *mf[] = { "no MFMA", "16x16x32_f16", "2 x 16x16x16_f16", "32x32x16_f16" };
     const char *pk[] = { "v_pk_mul_f32 op_sel:[0,1]", "v_pk_mov_b32 op_sel:[1,0]", "v_pk_mul_f32", "v_pk_add_f32 neg",
                          "v_pk_mul_f32 op_sel_hi:[0,1]", "v_pk_add_f32 neg -> v_pk_mov_b32 op_sel:[1,0]", "v_pk_mul_f32 op_sel:[1,0]",
                          "v_pk_mul_f32 op_sel:[1,1]", "v_pk_add_f32 op_sel:[0,1]", "v_pk_fma_f32 op_sel:[0,1,0]",
                          "v_pk_fma_f32 op_sel:[0,0,1]", "v_pk_mul_f32 op_sel_hi:[1,0]" };
     const int order[] = { 0, 6, 7, 8, 9, 10, 1, 5, 2, 3, 4, 11 };
-    for (int m = 0; m < 3; ++m)
+    for (int m = 0; m < 4; ++m)
         for (int q = 0; q < 12; ++q) {
             const int p = order[q];
             hipMemset(errs, 0, 32);
