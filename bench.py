@@ -6,8 +6,8 @@ config-2 workload: 800x800 D-NeRF "lego"-shaped synthetic scene, hash L=16 F=2 T
 per call (consecutive camera azimuths of a video render), every frame on its own render_image_test
 schedule.  With N GPUs every frame's rays are dealt tile-cyclically over the ranks under the ONE
 image-global schedule (survivor counts all-reduced per iteration) and the pixels are all-gathered over
-RCCL: the frames of a step are fixed, so the default is STRONG scaling (value(N) / value(1) is the speed-up;
---scaling weak renders that many frames per GPU instead).
+RCCL.  Default WEAK scaling: a call holds 16 x N frames (at most 64), so a rank's launches keep their size as N grows;
+--scaling strong keeps the step's frames fixed instead (the other mode is always reported beside the main figure).
 
 Default arithmetic since round 4: f16x2 -- all three MLPs on fp16 MFMA with every operand split into two fp16 numbers --
 because it now meets both bars: sample counts / opacity / depth / rgb BIT-IDENTICAL to the CPU oracle's mode of the same
@@ -78,14 +78,15 @@ def parse():
                          "800x800: 8 -> 16 +1.8 %, profiles/r03_sweep_frames_per_call.txt)")
     ap.add_argument("--frames-in-flight", type=int, default=3,
                     help="independent frames rendered concurrently per GPU (own stream + host thread each)")
-    ap.add_argument("--scaling", default=None, choices=["weak", "strong"],
-                    help="strong (default with several GPUs): a step renders frames_in_flight x frames_per_call frames IN "
-                         "TOTAL, every frame's rays dealt tile-cyclically over the GPUs (total work fixed: value(N) / "
-                         "value(1) is the speed-up); weak: that many frames PER GPU (per-GPU work fixed).  Either way a "
-                         "unit of a call is one rank's share of ONE frame and every frame runs the image-global "
-                         "render_image_test schedule (survivor counts all-reduced per iteration), so the gathered frames "
-                         "are bit-identical to single-GPU frames.  With several GPUs the other scaling is measured "
-                         "briefly afterwards and reported beside the main figure (`other_scaling`)")
+    ap.add_argument("--scaling", default="weak", choices=["weak", "strong"],
+                    help="weak (default): per-GPU work fixed -- a call holds frames_per_call x N frames (at most 64), every "
+                         "frame's rays dealt tile-cyclically over the N GPUs, so a rank's launches keep their single-GPU size "
+                         "as N grows; strong: a step renders frames_in_flight x frames_per_call frames IN TOTAL whatever N "
+                         "(value(N) / value(1) is then the speed-up on a fixed job; a rank's launches shrink with N).  Either "
+                         "way a unit of a call is one rank's share of ONE frame and every frame runs the image-global "
+                         "render_image_test schedule (survivor counts all-reduced per iteration), so the gathered frames are "
+                         "bit-identical to single-GPU frames.  With several GPUs the other mode is measured briefly afterwards "
+                         "and reported beside the main figure (`other_scaling`)")
     ap.add_argument("--min-seconds", type=float, default=2.0,
                     help="after the contractual K-step window, further K-step windows are timed until this much time has "
                          "been measured in all (at least 5, at most 24 windows): median / p10 / p90 in `windows`; "
@@ -235,8 +236,6 @@ def main():
     # A step renders `lanes` x `world` frames of a turntable video (consecutive azimuths): every lane is
     # one frame per GPU, its rays dealt tile-cyclically over the ranks; the lanes run concurrently.
     lanes = max(1, args.frames_in_flight)
-    if args.scaling is None:
-        args.scaling = "strong" if world > 1 else "weak"
     if args.frames_per_call <= 0:
         args.frames_per_call = max(8, min(32, int(round(10.24e6 / float(args.width * args.height)))))
     # A unit of a native call is this rank's share of ONE frame in both modes (the frame's loop is the whole image's,

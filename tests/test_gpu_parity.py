@@ -1908,7 +1908,7 @@ def test_bench_two_rank_rehearsal():
     exchange, frames in flight, the asynchronous pixel gather, the other precision modes, rank 0's JSON line with BOTH
     scalings.  The ranks share this box's one card, so the collectives run over gloo (CED_BENCH_BACKEND=gloo); with
     RCCL only the backend differs."""
-    d = _two_rank_bench(["--also", "f32+h16x2"])
+    d = _two_rank_bench(["--also", "f32+h16x2", "--scaling", "strong"])
     assert d["n_gpus"] == 2 and d["steps"] == 2 and d["scaling"] == "strong" and d["value"] > 0 and d["mlp_precision"] == "f16x2"
     assert d["config"]["frames_per_step"] == 9 and d["config"]["frames_per_call"] == 3 and "f32+h16x2" in d["other_mlp_precisions"]
     assert d["roofline"]["bound"] == "hbm" and 0 < d["roofline"]["frac"] < 1
@@ -1926,7 +1926,7 @@ def test_bench_two_rank_rehearsal():
 def test_bench_two_rank_rehearsal_weak_scaling():
     """The same launch line with --scaling weak: per-GPU work fixed (a call holds frames_per_call x ranks frames, a
     unit = one rank's share of ONE frame), the strong figure beside it."""
-    d = _two_rank_bench(["--also", "", "--scaling", "weak", "--no-single-frame"])
+    d = _two_rank_bench(["--also", "", "--no-single-frame"])             # weak is the default
     assert d["n_gpus"] == 2 and d["scaling"] == "weak" and d["config"]["frames_per_step"] == 18
     assert d["config"]["frames_per_call"] == 6 and d["other_scaling"]["scaling"] == "strong"
     _assert_gather_is_the_single_rank_render(d["gather_check"], 3)
