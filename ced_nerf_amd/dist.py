@@ -331,6 +331,8 @@ class PipelinedRenderer:
         import threading
 
         def issue(exchange, row, stream, iteration):
+            if self._abort is not None:    # the run this lane belongs to has failed or timed out: never issue on its own now
+                raise self._abort
             q = self._msgq
             if q is None:                  # the lane renders outside render / render_steps (lane.render_local): on its own
                 _all_reduce_on(row, stream, exchange.group)
@@ -475,7 +477,11 @@ class PipelinedRenderer:
             elif failure is None:
                 for t in threads:
                     t.result()
-            self._msgq = None
+            if failure is None:
+                self._msgq = None
+            # after a failure `_abort` stays set and the queues stay in place: a lane that is still inside a native call
+            # (a timeout does not wait for it) gets the error from its next request instead of issuing a collective itself.
+            # The renderer is not usable after an ExchangeTimeout (bench.py leaves the process).
         if failure is not None:
             raise failure
         return outs
