@@ -12,6 +12,7 @@ rays -- not a subset, not a self-comparison.
   C5  D-NeRF 800x800, fp16 features + fp16 MFMA MLPs     against the oracle's "f16" mode: schedule + counts + pixels BIT-EXACT
   C2h the same frame with split-fp16 MLPs (f16x2)        against the oracle's "f16x2" mode: the same, bit-exact; and against
                                                         the PLAIN fp32 oracle: same sample count, north-star 1e-4 on pixels
+  C3h / C4h  C3 / C4 in f16x2, every 2nd pixel            against the oracle's "f16x2" mode: schedule + counts + pixels bit-exact
 
 The oracle renders a frame in 5-15 s on the GPU box's host cores (OpenMP), 30-100 s in its fp16-operand modes (every
 product goes through the matrix-instruction model, oracle/mfma_f16_model.h).
@@ -173,3 +174,26 @@ def test_full_frame_half_precision_bitexact(oracle, tag, prec, kw):
     psnr = -10.0 * np.log10(max(mse, 1e-30))
     print(f"[{tag} {prec}] PSNR vs fp32 oracle {psnr:.1f} dB")
     assert psnr >= 120.0                                       # measured r02-r04: 139 dB
+
+
+@pytest.mark.parametrize("tag,name,w,h", [("C3h", "hypernerf", 536, 960), ("C4h", "dynerf", 1352, 1014)])
+def test_other_configurations_in_the_default_arithmetic(oracle, tag, name, w, h):
+    """C3 (HyperNeRF shape: -te -ta -df, two grid levels, cone marching, alpha threshold) and C4 (DyNeRF shape: four levels) in
+    `f16x2`, the arithmetic bench.py times, against the oracle's `f16x2` mode: schedule, sample total and every pixel bit for
+    bit, on every 2nd pixel in x and y of the full-size frame rendered as an image of its own (the whole frames in this
+    mode would be minutes of host time each; the fp32 rows above render them whole)."""
+    from ced_nerf_amd import ops
+    from ced_nerf_amd.utils import Rays, render_image_test
+    sc, of, oest, f, est, rays, rk = _setup(oracle, name, w, h, "f16x2", mlp_half="f16x2")
+    o = np.ascontiguousarray(sc["origins"][::2, ::2]); d = np.ascontiguousarray(sc["viewdirs"][::2, ::2])
+    trace = []
+    w_rgb, w_op, w_dp, w_total = oracle.render_image_test(1024, of, oest, o, d, timestamps=sc["timestamps"], trace=trace,
+                                                          **sc["render"])
+    tracer = ops.FrameTracer(capacity=1100, with_events=False)
+    rgb, op, dp, total = render_image_test(1024, f, est, Rays(T(o), T(d)), timestamps=T(sc["timestamps"]), tracer=tracer, **rk)
+    print(f"[{tag} f16x2] {o.shape[1]}x{o.shape[0]} rays: {total} samples in {len(trace)} iterations")
+    assert total == w_total and total > 100000
+    assert tracer.iterations() == [dict(n_alive=t["n_alive"], n_samples=t["n_samples"], n_new=t["n_new"]) for t in trace]
+    assert_bitexact(N(op), w_op, f"{tag} opacity")
+    assert_bitexact(N(dp), w_dp, f"{tag} depth")
+    assert_bitexact(N(rgb), w_rgb, f"{tag} rgb")
