@@ -668,6 +668,11 @@ def test_render_image_test_random_configurations(oracle, seed):
     from ced_nerf_amd.utils import render_image_test
     sc, cfg, rng = _fuzz_scene(seed)
     of, oest, f, est, rays, rk = _setup(oracle, sc)
+    # every third seed in one of the fp16-MFMA modes (CED_FUZZ_MODE forces one for a one-off run): against the oracle's mode
+    mode = os.environ.get("CED_FUZZ_MODE") or ("f32", "f32", "f16x2", "f32", "f32", "f16")[seed % 6]
+    if mode != "f32":
+        of = oracle.OracleField(sc["params"], mlp_half=mode)
+        f.set_mlp_precision(mode)
     max_samples = int(rng.choice([64, 300, 1024]))
     trace = []
     w_rgb, w_op, w_dp, w_total = oracle.render_image_test(max_samples, of, oest, sc["origins"], sc["viewdirs"],
@@ -687,6 +692,10 @@ def test_render_image_random_configurations(oracle, seed):
     from ced_nerf_amd.utils import render_image
     sc, cfg, rng = _fuzz_scene(100 + seed)
     of, oest, f, est, rays, rk = _setup(oracle, sc)
+    mode = os.environ.get("CED_FUZZ_MODE") or ("f32", "f16x2", "f32", "f32", "f16", "f32")[seed % 6]
+    if mode != "f32":
+        of = oracle.OracleField(sc["params"], mlp_half=mode)
+        f.set_mlp_precision(mode)
     w = oracle.render_image(of, oest, sc["origins"], sc["viewdirs"], timestamps=sc["timestamps"], **sc["render"])
     g = render_image(f, est, rays, timestamps=T(sc["timestamps"]), **rk)
     assert g[3] == w[3], (cfg, g[3], w[3])
