@@ -35,9 +35,12 @@ constexpr float kHalfMax = 65504.0f;
 // rsqrt here: 2-3 % faster, not reproducible on a CPU.)
 
 // eight fp32 values -> packed fp16 operand (and the fp16 remainder in F16X2 mode).  Two values at a time: ONE packed
-// conversion gives both high parts (v_cvt_pk_f16_f32, round to nearest even like the scalar form), which are widened
-// back for the remainders straight out of the packed register -- the scalar formulation converted every value twice
-// (once alone for the remainder, once more for the pack): 5 vector instructions per value instead of 4.
+// conversion gives both high parts (v_cvt_pk_f16_f32, round to nearest even like the scalar form).  The remainder
+// lo = fp16(x - fp32(hi)) is ONE instruction per value, v_fma_mixlo_f16 / v_fma_mixhi_f16 computing fp16(hi * -1.0 + x)
+// straight from the packed high part: x - hi is exact in fp32 (hi is x rounded to 11 bits), so rounding the fused
+// result once to fp16 is rounding the same real number as the two-step form the oracle states
+// (tools/probes/split_mix_exhaustive.hip: all 2^32 patterns agree).  Per value 1.5 vector instructions for the split
+// (+ 1 for the ReLU / saturation of to_operand_h); rounds 1-3: 4, round 4 before this: 2.5.
 typedef _Float16 h2 __attribute__((ext_vector_type(2)));
 typedef float f2v __attribute__((ext_vector_type(2)));
 template <bool SPLIT> __device__ __forceinline__ void to_half8(const float (&v)[8], h8 &hi, h8 &lo)
@@ -45,8 +48,9 @@ template <bool SPLIT> __device__ __forceinline__ void to_half8(const float (&v)[
 #pragma unroll
     for (int e = 0; e < 8; e += 2) {
         // The values are made opaque first: left visible, hipcc folds a producing multiply / fma into the conversion
-        // (v_fma_mixlo_f16), which rounds ONCE to fp16 instead of to fp32 and then to fp16 -- a different result
-        // whenever the fp32 value is an fp16 tie (found in round 4: the SH inputs of the f16 kernels, 1 value in 8192).
+        // (v_fma_mixlo_f16 with a multiplier other than 1), which rounds ONCE to fp16 instead of to fp32 and then to
+        // fp16 -- a different result whenever the fp32 value is an fp16 tie (found in round 4: the SH inputs of the f16
+        // kernels, 1 value in 8192).  tools/isa_lint.py allows the mix forms only in the shape of the remainder below.
         float x0 = v[e], x1 = v[e + 1];
         asm("" : "+v"(x0));
         asm("" : "+v"(x1));
@@ -54,10 +58,14 @@ template <bool SPLIT> __device__ __forceinline__ void to_half8(const float (&v)[
         hi[e] = h[0];
         hi[e + 1] = h[1];
         if constexpr (SPLIT) {
-            const f2v back = __builtin_convertvector(h, f2v);
-            const h2 l = __builtin_convertvector(f2v{ x0, x1 } - back, h2);       // exact differences, one packed subtract
-            lo[e] = l[0];
-            lo[e + 1] = l[1];
+            // fptrunc(fma(fpext(hi), m1, x)) is the pattern hipcc selects v_fma_mix{lo,hi}_f16 for; m1 = -1.0 is kept
+            // opaque in a scalar register, or the middle end turns the fma into a subtraction (three instructions again).
+            // NOT inline assembly: the hazard recogniser does not see through it, and an MFMA that reads the remainder
+            // less than two wait states after the write takes the stale register (seen with the fp16-table kernels).
+            float m1 = -1.0f;
+            asm("" : "+s"(m1));
+            lo[e] = (_Float16)__builtin_fmaf((float)h[0], m1, x0);
+            lo[e + 1] = (_Float16)__builtin_fmaf((float)h[1], m1, x1);
         }
     }
 }

@@ -19,7 +19,10 @@ FORBIDDEN = re.compile(r"\b(v_pk_(?:mul|add|fma|min|max)_f32)\b[^\n]*?\bop_sel:\
                        # second rule (round 4): a multiply / fma folded into the fp32 -> fp16 conversion rounds ONCE to fp16;
                        # the CPU oracle (and the C standard) round to fp32 first.  field_half_device.hpp::to_half8 pins
                        # its inputs so that hipcc cannot form it; this keeps an edit from bringing it back.
-                       r"|\bv_(?:fma|mad)_mix(?:lo|hi)_f16\b")
+                       # The ONE allowed use is the operand split's remainder, fp16(hi * m1 + x) with hi an fp16 source, m1 = -1.0
+                       # in a scalar register and x an fp32 register (the fused result is the exact difference rounded once:
+                       # tools/probes/split_mix_exhaustive.hip); a multiply folded by the compiler has fp32 sources.
+                       r"|\bv_(?:fma|mad)_mix(?:lo|hi)_f16\b(?!\s+v\d+,\s*v\d+,\s*s\d+,\s*v\d+\s+(?:op_sel:\[1,0,0\]\s+)?op_sel_hi:\[1,0,0\])")
 
 
 def code_objects(path):
