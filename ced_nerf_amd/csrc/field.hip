@@ -336,7 +336,7 @@ __global__ __launch_bounds__(256) void hash_backward_kernel(HashBwdArgs A)
 // Diagnostic knobs of ced_set_option: process-wide, read by concurrently rendering threads -> atomics (relaxed: each is
 // an independent launch property; no setting changes a result).
 std::atomic<int> g_field_stagger{ 0 };          // field kernel: start-up phase offset between the waves of a SIMD, in s_sleep(127) units
-std::atomic<int> g_field_spread_tiles{ 1 };     // field kernels: deal tiles across all CUs first
+std::atomic<int> g_field_spread_tiles{ 2 };     // field kernels: tile -> wave mapping (field_device.hpp: field_tile_range)
 std::atomic<int> g_march_early_out{ 1 };        // frame renderer: conservative brick-level early-out
 std::atomic<int> g_march_two_pass{ -1 };        // frame renderer: first iteration as culling pass + marching of the rest (-1: when there are several grid levels)
 
@@ -459,7 +459,8 @@ extern "C" int ced_set_option(const char *key, int value)
         return CED_OK;
     }
     if (strcmp(key, "field_spread_tiles") == 0) {
-        ced::g_field_spread_tiles = value != 0;
+        CED_REQUIRE(value >= 0 && value <= 2, "set_option: field_spread_tiles must be 0, 1 or 2 (field_tile_range)");
+        ced::g_field_spread_tiles = value;
         return CED_OK;
     }
     if (strcmp(key, "march_early_out") == 0) {

@@ -12,6 +12,38 @@ namespace ced {
 typedef float f4 __attribute__((ext_vector_type(4)));
 typedef float f2 __attribute__((ext_vector_type(2)));
 
+// Tile -> wave mapping of the persistent field kernels (one workgroup per CU, WAVES waves, tiles of 16 * NT samples).
+// mode 0: wave w of workgroup b takes tiles b * WAVES + w, + gridDim.x * WAVES, ...
+// mode 1: a round of gridDim.x * WAVES tiles is dealt in groups of four consecutive tiles (the four SIMDs of a CU) across
+//         ALL workgroups before any workgroup gets a second group.  The last, partial round of a launch (a frame's
+//         launches are 4-5 rounds long) then leaves every CU with about one wave per SIMD -- which runs ~2.5x faster than
+//         three sharing the MFMA pipe -- instead of a third of the CUs fully loaded and the rest idle.
+// mode 2 (default; needs gridDim.x % 8 == 0, else mode 1): the same dealing inside each XCD.  Workgroup b runs on XCD
+//         b % 8; the eight XCDs take eight CONTIGUOUS parts of the sample stream, so a table line wanted by
+//         neighbouring samples (adjacent samples of a ray, adjacent rays of a pixel tile) is fetched into ONE L2
+//         instead of up to eight (round 4: +2 % f16x2, +9 % f16 on a 15 M-sample launch).
+// Returns false when the workgroup has no tile at all (it leaves before staging anything).
+struct TileRange { int64_t first, end, stride; };
+__device__ __forceinline__ bool field_tile_range(int mode, int64_t n_tiles, int waves, int wave, TileRange &r)
+{
+    const int64_t grid = gridDim.x, b = blockIdx.x;
+    if (mode == 2 && (grid & 7) == 0) {
+        const int64_t n_groups = (n_tiles + 3) >> 2, per_xcd = grid >> 3, region = (n_groups + 7) >> 3;
+        const int64_t start = (b & 7) * region;
+        const int64_t g_end = start + region < n_groups ? start + region : n_groups;
+        if (start + (b >> 3) >= g_end) return false;
+        r.first = (start + (int64_t)(wave >> 2) * per_xcd + (b >> 3)) * 4 + (wave & 3);
+        r.end = 4 * g_end < n_tiles ? 4 * g_end : n_tiles;
+        r.stride = (int64_t)(waves / 4) * per_xcd * 4;
+        return true;
+    }
+    if ((mode ? b * 4 : b * waves) >= n_tiles) return false;
+    r.first = mode ? ((int64_t)(wave >> 2) * grid + b) * 4 + (wave & 3) : b * waves + wave;
+    r.end = n_tiles;
+    r.stride = grid * waves;
+    return true;
+}
+
 // Per-level constants, pre-multiplied by the table's bytes per entry (a power of two), so the
 // corner arithmetic below produces byte offsets directly: the xor-hash commutes with the shift
 // ((a^b) << s == (a<<s) ^ (b<<s)) and the dense index is linear.
@@ -125,7 +157,11 @@ __device__ __forceinline__ void hash_level(const LevelConst &L, const void *__re
             db = dx < dw ? dx : dw;
         }
         const uint32_t idxb = (MODE == 1) ? db : (MODE == 2) ? hb : (hashed ? hb : db);
+#ifdef CED_AB_GATHER_WINDOW            // diagnostic builds (tools/ab_build.sh): the gathers of a level confined to a byte window
+        off[c] = L.offb + (idxb & (uint32_t)(CED_AB_GATHER_WINDOW));
+#else
         off[c] = L.offb + idxb;
+#endif
         w[c] = wxy[cx + 2 * cy] * (cz ? fr[2] : om[2]);
     }
     const char *tb = reinterpret_cast<const char *>(table);

@@ -73,8 +73,9 @@ __global__ __launch_bounds__(THREADS) void field_half_kernel(FieldArgs A)
     // the by-value argument block would make the compiler keep the whole block in scratch.)
     const int64_t sbase = A.base_dev ? *A.base_dev : 0;
     const int64_t n_tiles = (n_eff + TILE - 1) / TILE;
-    // a workgroup without a tile leaves before staging anything (see field.hip)
-    if ((A.spread_tiles ? (int64_t)blockIdx.x * 4 : (int64_t)blockIdx.x * WAVES) >= n_tiles) return;
+    // a workgroup without a tile leaves before staging anything (field_device.hpp: field_tile_range)
+    TileRange tiles;
+    if (!field_tile_range(A.spread_tiles, n_tiles, WAVES, wave, tiles)) return;
     if (A.stamp && tid == 0) atomicMin(A.stamp, (unsigned long long)wall_clock64());
 
     {
@@ -92,10 +93,7 @@ __global__ __launch_bounds__(THREADS) void field_half_kernel(FieldArgs A)
 
     const float extent[3] = { A.aabb[3] - A.aabb[0], A.aabb[4] - A.aabb[1], A.aabb[5] - A.aabb[2] };
 
-    // tiles are dealt in groups of four (one per SIMD) across all workgroups first: see field.hip
-    const int64_t first_tile = A.spread_tiles ? ((int64_t)(wave >> 2) * gridDim.x + blockIdx.x) * 4 + (wave & 3)
-                                              : (int64_t)blockIdx.x * WAVES + wave;
-    for (int64_t tile = first_tile; tile < n_tiles; tile += (int64_t)gridDim.x * WAVES) {
+    for (int64_t tile = tiles.first; tile < tiles.end; tile += tiles.stride) {
         // opaque LDS base per tile: keeps the A-fragment reads inside the loop (see field.hip)
         int lds_off = 0;
         asm volatile("" : "+v"(lds_off));

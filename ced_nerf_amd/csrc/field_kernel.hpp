@@ -137,8 +137,9 @@ __global__ __launch_bounds__(THREADS) void field_kernel(FieldArgs A)
     const int64_t sbase = A.base_dev ? *A.base_dev : 0;
     const int64_t n_tiles = (n_eff + TILE - 1) / TILE;
     // a workgroup without a tile leaves before staging anything (launches are sized by a host-side upper bound of
-    // the sample count; the exact count comes from device memory)
-    if ((A.spread_tiles ? (int64_t)blockIdx.x * 4 : (int64_t)blockIdx.x * FIELD_WAVES) >= n_tiles) return;
+    // the sample count; the exact count comes from device memory); tile -> wave mapping: field_device.hpp
+    TileRange tiles;
+    if (!field_tile_range(A.spread_tiles, n_tiles, FIELD_WAVES, threadIdx.x >> 6, tiles)) return;
     if (A.stamp && tid == 0) atomicMin(A.stamp, (unsigned long long)wall_clock64());
 
     // stage weights + level tables into LDS
@@ -172,14 +173,7 @@ __global__ __launch_bounds__(THREADS) void field_kernel(FieldArgs A)
         for (int S = 6; S < 8; ++S) t_feat[S - 6] = det_sinpi_phase(t_all * (float)(1 << (2 * (S & 1) + (g >> 1))), g & 1);
     }
 
-    // Tile -> wave mapping: a round of gridDim.x * WAVES tiles is dealt in groups of four consecutive tiles
-    // (the four SIMDs of a CU) across ALL workgroups before any workgroup gets a second group.  The last,
-    // partial round of a launch (a frame's launches are 4-5 rounds long) then leaves every CU with about one
-    // wave per SIMD -- which runs ~2.5x faster than three sharing the MFMA pipe -- instead of a third of the
-    // CUs fully loaded and the rest idle.
-    const int64_t first_tile = A.spread_tiles ? ((int64_t)(wave >> 2) * gridDim.x + blockIdx.x) * 4 + (wave & 3)
-                                              : (int64_t)blockIdx.x * FIELD_WAVES + wave;
-    for (int64_t tile = first_tile; tile < n_tiles; tile += (int64_t)gridDim.x * FIELD_WAVES) {
+    for (int64_t tile = tiles.first; tile < tiles.end; tile += tiles.stride) {
         // Re-derive the LDS weight base every tile through an opaque register: the A fragments sit at
         // tile-invariant addresses and the compiler would otherwise hoist all ~80 ds_read_b128 out of
         // the persistent loop and park them in scratch.
