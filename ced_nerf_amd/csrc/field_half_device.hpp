@@ -98,39 +98,53 @@ __device__ __forceinline__ f4 mfma_k32(const h8 &a, const h8 &b, f4 c)
 #endif
 }
 
+// One layer: D^T[nb] = sum over k-steps of W[nb][ks] * X^T[ks], NB * KS groups of (SPLIT ? 3 : 1) * NT product blocks.
+// The A fragments of group g + 1 are fetched from LDS BEFORE the MFMAs of group g issue (two fragment pairs alive: 8
+// registers more): fetched where they are used -- rounds 1-4 -- every group began with ~100 cycles of exposed LDS latency,
+// once per 12 MFMAs (192 cycles of the matrix pipe).
 template <int KS, int NB, int NT, bool SPLIT>
 __device__ __forceinline__ void mlp_layer_h(const _Float16 *__restrict__ whi, const _Float16 *__restrict__ wlo, int lane,
                                             const h8 (&Bh)[NT][2], const h8 (&Bl)[NT][2], f4 (&D)[NT][4])
 {
+    constexpr int G = NB * KS;
+    h8 ah = *reinterpret_cast<const h8 *>(whi + lane * 8);
+    h8 al = ah;
+    if constexpr (SPLIT) al = *reinterpret_cast<const h8 *>(wlo + lane * 8);
+    f4 acc[NT];
 #pragma unroll
-    for (int nb = 0; nb < NB; ++nb) {
-        f4 acc[NT];
+    for (int grp = 0; grp < G; ++grp) {
+        const int nb = grp / KS, ks = grp % KS;
+        if (ks == 0) {
 #pragma unroll
-        for (int j = 0; j < NT; ++j) acc[j] = f4{ 0.0f, 0.0f, 0.0f, 0.0f };
+            for (int j = 0; j < NT; ++j) acc[j] = f4{ 0.0f, 0.0f, 0.0f, 0.0f };
+        }
+        h8 ah_next = ah, al_next = al;
+        if (grp + 1 < G) {
+            ah_next = *reinterpret_cast<const h8 *>(whi + ((grp + 1) * 64 + lane) * 8);
+            if constexpr (SPLIT) al_next = *reinterpret_cast<const h8 *>(wlo + ((grp + 1) * 64 + lane) * 8);
+            else al_next = ah_next;
+        }
+        if constexpr (SPLIT) {
 #pragma unroll
-        for (int ks = 0; ks < KS; ++ks) {
-            const h8 ah = *reinterpret_cast<const h8 *>(whi + ((nb * KS + ks) * 64 + lane) * 8);
-            h8 al = ah;
-            if constexpr (SPLIT) {
-                al = *reinterpret_cast<const h8 *>(wlo + ((nb * KS + ks) * 64 + lane) * 8);
+            for (int j = 0; j < NT; ++j) acc[j] = mfma_k32(al, Bh[j][ks], acc[j]);
 #pragma unroll
-                for (int j = 0; j < NT; ++j) acc[j] = mfma_k32(al, Bh[j][ks], acc[j]);
-#pragma unroll
-                for (int j = 0; j < NT; ++j) acc[j] = mfma_k32(ah, Bl[j][ks], acc[j]);
-            }
-#pragma unroll
-            for (int j = 0; j < NT; ++j) acc[j] = mfma_k32(ah, Bh[j][ks], acc[j]);
-            // Group fence: the MFMAs of a group issue back to back; it keeps the conversions of the next operands
-            // out of the MFMA stream (the pad and the operand pins are left-overs of round 1's hunt for the hazard
-            // described at mfma_k32 and cost nothing measurable).
-            __builtin_amdgcn_sched_barrier(0);
-            asm volatile("s_nop %0" ::"n"(CED_HALF_MFMA_GUARD));
-            asm volatile("" ::"v"(ah));
-            if constexpr (SPLIT) asm volatile("" ::"v"(al));
-            __builtin_amdgcn_sched_barrier(0);
+            for (int j = 0; j < NT; ++j) acc[j] = mfma_k32(ah, Bl[j][ks], acc[j]);
         }
 #pragma unroll
-        for (int j = 0; j < NT; ++j) D[j][nb] = acc[j];
+        for (int j = 0; j < NT; ++j) acc[j] = mfma_k32(ah, Bh[j][ks], acc[j]);
+        // Group fence: the MFMAs of a group issue back to back; it keeps the conversions of the next operands
+        // out of the MFMA stream (the operand pins are left-overs of round 1's hunt for the hazard described at
+        // mfma_k32 and cost nothing measurable).
+        __builtin_amdgcn_sched_barrier(0);
+        asm volatile("" ::"v"(ah));
+        if constexpr (SPLIT) asm volatile("" ::"v"(al));
+        __builtin_amdgcn_sched_barrier(0);
+        if (ks == KS - 1) {
+#pragma unroll
+            for (int j = 0; j < NT; ++j) D[j][nb] = acc[j];
+        }
+        ah = ah_next;
+        al = al_next;
     }
     // the same for the B operands, whose last readers are the MFMAs of the last group
 #pragma unroll
