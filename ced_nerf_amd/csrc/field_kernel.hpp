@@ -50,25 +50,33 @@ __device__ __forceinline__ void mlp_layer(const float *__restrict__ wl, int lane
                                           f4 (&D)[NT][4])
 {
     constexpr int KS4 = ks4_of(KS);
+    constexpr int G = NB * KS4;
+    // the A fragment of group g + 1 (four k-steps of one 16-neuron block) is fetched from LDS before the MFMAs of group g
+    // issue: fetched where it is used, every group began with the LDS latency exposed (as in field_half_device.hpp)
+    f4 a = *reinterpret_cast<const f4 *>(wl + lane * 4);
+    f4 acc[NT];
 #pragma unroll
-    for (int nb = 0; nb < NB; ++nb) {
-        f4 acc[NT];
+    for (int grp = 0; grp < G; ++grp) {
+        const int nb = grp / KS4, q = grp % KS4;
+        if (q == 0) {
 #pragma unroll
-        for (int j = 0; j < NT; ++j) acc[j] = f4{ 0.0f, 0.0f, 0.0f, 0.0f };
+            for (int j = 0; j < NT; ++j) acc[j] = f4{ 0.0f, 0.0f, 0.0f, 0.0f };
+        }
+        f4 a_next = a;
+        if (grp + 1 < G) a_next = *reinterpret_cast<const f4 *>(wl + ((grp + 1) * 64 + lane) * 4);
 #pragma unroll
-        for (int q = 0; q < KS4; ++q) {
-            const f4 a = *reinterpret_cast<const f4 *>(wl + ((nb * KS4 + q) * 64 + lane) * 4);
+        for (int s = 0; s < 4; ++s) {
+            if (4 * q + s < KS) {
 #pragma unroll
-            for (int s = 0; s < 4; ++s) {
-                if (4 * q + s < KS) {
-#pragma unroll
-                    for (int j = 0; j < NT; ++j)
-                        acc[j] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[s], B[j][4 * q + s], acc[j], 0, 0, 0);
-                }
+                for (int j = 0; j < NT; ++j)
+                    acc[j] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[s], B[j][4 * q + s], acc[j], 0, 0, 0);
             }
         }
+        if (q == KS4 - 1) {
 #pragma unroll
-        for (int j = 0; j < NT; ++j) D[j][nb] = acc[j];
+            for (int j = 0; j < NT; ++j) D[j][nb] = acc[j];
+        }
+        a = a_next;
     }
 }
 
