@@ -473,7 +473,7 @@ extern "C" int ced_set_option(const char *key, int value)
         return CED_OK;
     }
     if (strcmp(key, "half_variant") == 0) {
-        CED_REQUIRE(value >= 0 && value <= 2, "set_option: half_variant must be 0..2");
+        CED_REQUIRE(value >= 0 && value <= 3, "set_option: half_variant must be 0..2 (3: diagnostic builds only)");
         ced::set_half_variant(value);
         return CED_OK;
     }

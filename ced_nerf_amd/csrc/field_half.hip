@@ -350,12 +350,18 @@ int launch_field_half(FieldArgs &A, int time_mode, int precision, void *stream)
         switch (half_variant) {
         case 1: CED_HALF_CASE(true, 2, 512) break;
         case 2: CED_HALF_CASE(true, 2, 1024) break;
+#ifdef CED_AB_HALF_NT1
+        case 3: CED_HALF_CASE(true, 1, 1024) break;
+#endif
         default: CED_HALF_CASE(true, 2, 768) break;
         }
     } else {
         switch (half_variant) {
         case 1: CED_HALF_CASE(false, 2, 512) break;
         case 2: CED_HALF_CASE(false, 2, 1024) break;
+#ifdef CED_AB_HALF_NT1
+        case 3: CED_HALF_CASE(false, 1, 1024) break;
+#endif
         default: CED_HALF_CASE(false, 2, 768) break;
         }
     }
