@@ -433,6 +433,34 @@ def test_field_forward_large_persistent_launch(oracle):
         assert_bitexact(N(rgb[pk]), w_rgb, f"rgb (large launch, {prec})")
 
 
+def test_field_tile_mappings_agree():
+    """The tile -> wave mapping of the persistent field kernels (field_device.hpp: field_tile_range; option
+    field_spread_tiles 0 / 1 / 2 = XCD-contiguous) and the workgroup count of a launch are launch properties: every
+    combination must cover every sample exactly once, i.e. give the bits of the default launch -- for sample counts around
+    the tile, group and XCD-region boundaries, in the exact and the default arithmetic."""
+    from ced_nerf_amd import _lib, ops, synthetic as S
+    from ced_nerf_amd.model import DNGPradianceField
+    p = S.init_field_params([-1, -1, -1, 1, 1, 1], 1e-3, 1024, 15, regime="trained")
+    f = DNGPradianceField.from_params(p, DEV).eval()
+    rng = np.random.default_rng(11)
+    try:
+        for n in (1, 31, 33, 127, 129, 1023, 4097, 40001, 300007):
+            pos = T(rng.uniform(-1, 1, size=(n, 3)).astype(np.float32))
+            t = T(rng.uniform(0, 1, size=(n, 1)).astype(np.float32))
+            d = T(rng.normal(size=(n, 3)).astype(np.float32))
+            for prec in ("f32", "f16x2"):
+                f.set_mlp_precision(prec)
+                _lib.check(_lib.lib().ced_set_option(b"field_spread_tiles", 2))
+                rgb0, sig0 = ops.field_forward(f._descriptor(), pos, t, d)[:2]
+                for spread in (0, 1, 2):
+                    _lib.check(_lib.lib().ced_set_option(b"field_spread_tiles", spread))
+                    for wgs in (0, 8, 13, 40, 256):
+                        out = ops.field_forward(ops._with_workgroups(f._descriptor(), wgs), pos, t, d)
+                        assert torch.equal(out[0], rgb0) and torch.equal(out[1], sig0), (n, prec, spread, wgs)
+    finally:
+        _lib.check(_lib.lib().ced_set_option(b"field_spread_tiles", 2))
+
+
 def test_field_small_and_empty(oracle):
     from ced_nerf_amd import synthetic as S
     from ced_nerf_amd.model import DNGPradianceField
