@@ -345,7 +345,11 @@ int launch_field_half(FieldArgs &A, int time_mode, int precision, void *stream)
     case 6: launch(field_half_kernel<false, true, true, SP_, NT_, TH_>, NT_, TH_); break;                       \
     default: launch(field_half_kernel<true, true, true, SP_, NT_, TH_>, NT_, TH_); break;                       \
     }
-    const int half_variant = g_half_variant.load(std::memory_order_relaxed);
+    // 768 threads (three waves per SIMD, 168 registers) is the default; the time-embedding and temporal-table kernels
+    // spill at that cap (16-100 registers) and run two waves per SIMD without scratch instead (C3 +1.7 %, C4 +4 %), as
+    // the fp32 kernels do (field.hip)
+    const int requested_variant = g_half_variant.load(std::memory_order_relaxed);
+    const int half_variant = (requested_variant == 0 && (time_mode || A.temporal)) ? 1 : requested_variant;
     if (precision == CED_MLP_F16X2) {
         switch (half_variant) {
         case 1: CED_HALF_CASE(true, 2, 512) break;
