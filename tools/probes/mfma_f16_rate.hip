@@ -26,7 +26,9 @@ template <int FORM> __global__ __launch_bounds__(256) void rate(float *out, long
             if (FORM == 0) asm volatile("v_mfma_f32_16x16x16_f16 %0, %1, %2, %0" : "+v"(acc[k]) : "v"(a0), "v"(b0));
             else if (FORM == 1) asm volatile("v_mfma_f32_16x16x32_f16 %0, %1, %2, %0" : "+v"(acc[k]) : "v"(a), "v"(b));
             else if (FORM == 2) asm volatile("v_mfma_f32_32x32x8_f16 %0, %1, %2, %0" : "+v"(big[k & 3]) : "v"(a0), "v"(b0));
-            else asm volatile("v_mfma_f32_4x4x4_16b_f16 %0, %1, %2, %0" : "+v"(acc[k]) : "v"(a0), "v"(b0));
+            else if (FORM == 3) asm volatile("v_mfma_f32_4x4x4_16b_f16 %0, %1, %2, %0" : "+v"(acc[k]) : "v"(a0), "v"(b0));
+            else if (FORM == 4) asm volatile("v_mfma_f32_16x16x16_f16 %0, %1, %2, %0" : "+v"(acc[0]) : "v"(a0), "v"(b0));      // one dependent chain
+            else asm volatile("v_mfma_f32_16x16x16_f16 %0, %1, %2, %0" : "+v"(acc[k >> 1 & 1]) : "v"(a0), "v"(b0));         // pairs: a a b b a a b b
         }
     }
     asm volatile("s_nop 15\n s_nop 15" ::: "memory");
@@ -43,21 +45,23 @@ int main()
     float *out; long long *cyc;
     hipMalloc(&out, 256 * 256 * 4); hipMalloc(&cyc, 256 * 8);
     const int iters = 20000;
-    for (int form = 0; form < 4; ++form) {
+    for (int form = 0; form < 6; ++form) {
         hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
         for (int rep = 0; rep < 2; ++rep) {
             hipEventRecord(e0);
             if (form == 0) hipLaunchKernelGGL(rate<0>, dim3(256), dim3(256), 0, 0, out, cyc, iters);
             else if (form == 1) hipLaunchKernelGGL(rate<1>, dim3(256), dim3(256), 0, 0, out, cyc, iters);
             else if (form == 2) hipLaunchKernelGGL(rate<2>, dim3(256), dim3(256), 0, 0, out, cyc, iters);
-            else hipLaunchKernelGGL(rate<3>, dim3(256), dim3(256), 0, 0, out, cyc, iters);
+            else if (form == 3) hipLaunchKernelGGL(rate<3>, dim3(256), dim3(256), 0, 0, out, cyc, iters);
+            else if (form == 4) hipLaunchKernelGGL(rate<4>, dim3(256), dim3(256), 0, 0, out, cyc, iters);
+            else hipLaunchKernelGGL(rate<5>, dim3(256), dim3(256), 0, 0, out, cyc, iters);
             hipEventRecord(e1); hipEventSynchronize(e1);
         }
         float ms; hipEventElapsedTime(&ms, e0, e1);
         long long h[256]; hipMemcpy(h, cyc, sizeof h, hipMemcpyDeviceToHost);
         const double n = 8.0 * iters;
         printf("%s: %.3f ms for %d MFMAs per wave, one wave per SIMD -> %.2f ns per MFMA per SIMD; clock64 ticks per MFMA %.2f\n",
-               form == 0 ? "v_mfma_f32_16x16x16_f16" : form == 1 ? "v_mfma_f32_16x16x32_f16" : form == 2 ? "v_mfma_f32_32x32x8_f16" : "v_mfma_f32_4x4x4_16b_f16", ms, (int)n, ms * 1e6 / n, (double)h[0] / n);
+               form == 0 ? "v_mfma_f32_16x16x16_f16" : form == 1 ? "v_mfma_f32_16x16x32_f16" : form == 2 ? "v_mfma_f32_32x32x8_f16" : form == 3 ? "v_mfma_f32_4x4x4_16b_f16" : form == 4 ? "16x16x16_f16, ONE dependent chain" : "16x16x16_f16, dependent pairs (a a b b)", ms, (int)n, ms * 1e6 / n, (double)h[0] / n);
     }
     return 0;
 }
