@@ -60,7 +60,9 @@ __global__ __launch_bounds__(THREADS) void field_half_kernel(FieldArgs A)
     __shared__ __attribute__((aligned(16))) _Float16 lds[WHALVES + 16 * CED_MAX_LEVELS];
     const int tid = threadIdx.x;
     const int lane = tid & 63;
-    const int wave = tid >> 6;
+    // the wave's number as a SCALAR: everything derived from it (the wave's tiles, their sample ranges, the bases of the
+    // per-sample arrays) then lives in scalar registers and the per-lane part of an index is a 32-bit offset
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int g = lane >> 4, c = lane & 15;
 
     int64_t n_eff = A.n;
@@ -99,15 +101,18 @@ __global__ __launch_bounds__(THREADS) void field_half_kernel(FieldArgs A)
         asm volatile("" : "+v"(lds_off));
         const _Float16 *const whi = lds + lds_off;
         const _Float16 *const wlo = whi + PLANE;
-        int64_t sidx[NT];
+        // sample s of the call = tile_base + lane offset; a ragged last tile repeats its last sample (never stored)
+        const int64_t tile_base = tile * TILE;
+        const int64_t left = n_eff - tile_base;
+        const int in_tile = left < TILE ? (int)left : TILE;                  // 1 .. TILE, scalar
+        int sofs[NT];
         int64_t ridx[NT];
         float px[NT][3], tq[NT];
         bool any_used = !A.rays_mode;
 #pragma unroll
         for (int j = 0; j < NT; ++j) {
-            int64_t s = tile * TILE + 16 * j + c;
-            s = s < n_eff ? s : n_eff - 1;
-            sidx[j] = s;
+            sofs[j] = 16 * j + c < in_tile ? 16 * j + c : in_tile - 1;
+            const int64_t s = tile_base + sofs[j];
             if (A.rays_mode) {
                 // negative ray index = unused sample slot (see field.hip)
                 const int64_t r_in = A.ray_idx32 ? (int64_t)A.ray_idx32[sbase + s] : A.ray_idx[sbase + s];
@@ -234,11 +239,12 @@ __global__ __launch_bounds__(THREADS) void field_half_kernel(FieldArgs A)
         // accumulator row 4g + r: geometry feature 4g + r; row 15 (g = 3, r = 3): raw density
 #pragma unroll
         for (int j = 0; j < NT; ++j) {
-            const int64_t s = tile * TILE + 16 * j + c;
+            const bool stored = 16 * j + c < in_tile;
+            const int64_t s = tile_base + (16 * j + c);
             float sg = det_expf(D[j][0][3] - 1.0f);            // trunc_exp(raw - 1) * selector
             sg = sel[j] ? sg : 0.0f;
-            if (g == 3 && s < n_eff) A.sigma[sbase + s] = sg;
-            if (A.geo && s < n_eff) {
+            if (g == 3 && stored) A.sigma[sbase + s] = sg;
+            if (A.geo && stored) {
 #pragma unroll
                 for (int r = 0; r < 4; ++r)
                     if (4 * g + r < 15) A.geo[s * 15 + 4 * g + r] = D[j][0][r];
@@ -252,7 +258,7 @@ __global__ __launch_bounds__(THREADS) void field_half_kernel(FieldArgs A)
                 float dv[3];
 #pragma unroll
                 for (int a = 0; a < 3; ++a)
-                    dv[a] = A.rays_mode ? A.rays_d[3 * ridx[j] + a] : A.dir[3 * sidx[j] + a];
+                    dv[a] = A.rays_mode ? A.rays_d[3 * ridx[j] + a] : A.dir[3 * (tile_base + sofs[j]) + a];
                 const float nrm = __builtin_sqrtf((dv[0] * dv[0] + dv[1] * dv[1]) + dv[2] * dv[2]);
                 // lane group g feeds SH coefficient g: only that direction component is normalised (as field_kernel.hpp)
                 const float comp = (g == 1) ? dv[1] : (g == 2) ? dv[2] : dv[0];
@@ -275,10 +281,10 @@ __global__ __launch_bounds__(THREADS) void field_half_kernel(FieldArgs A)
             mlp_layer_h<2, 1, NT, SPLIT>(whi + BL::H2 * kFragHalves, wlo + BL::H2 * kFragHalves, lane, Bh, Bl, D);
 #pragma unroll
             for (int j = 0; j < NT; ++j) {
-                const int64_t s = tile * TILE + 16 * j + c;
+                const int64_t s = tile_base + (16 * j + c);
                 // the packer put colour channel a on accumulator row 4a = (lane group a, register 0): one sigmoid per lane
                 const float o1 = 1.0f / (1.0f + det_expf(-D[j][0][0]));
-                if (g < 3 && s < n_eff) A.rgb[3 * (sbase + s) + g] = o1;
+                if (g < 3 && 16 * j + c < in_tile) A.rgb[3 * (sbase + s) + g] = o1;
             }
         }
     }
