@@ -343,7 +343,7 @@ std::atomic<int> g_march_two_pass{ -1 };        // frame renderer: first iterati
 // launch-geometry variant of the field kernel (ced_set_option("field_variant", v))
 static std::atomic<int> g_hash_grad_blocks{ [] { const char *e = getenv("CED_HASH_GRAD_BLOCKS"); return e ? atoi(e) : 0; }() };
 static std::atomic<int> g_hash_grad_form{ []  { const char *e = getenv("CED_HASH_GRAD_FORM"); return e ? atoi(e) : 1; }() };   // 0: one corner per instruction
-static std::atomic<int> g_field_variant{ [] { const char *e = getenv("CED_FIELD_VARIANT"); return e ? atoi(e) : 2; }() };
+static std::atomic<int> g_field_variant{ [] { const char *e = getenv("CED_FIELD_VARIANT"); return e ? atoi(e) : 3; }() };
 
 static int validate_hash(const ced_hash_desc *h, const char *who)
 {
@@ -394,12 +394,21 @@ int launch_field(const ced_field_desc *d, FieldArgs &A, void *stream)
         A.size[l] = d->hash.size[l];
         A.hashed[l] = d->hash.hashed[l];
     }
-    // per gather slot i: levels 4i..4i+3: 1 = all dense, 2 = all hashed, 0 = mixed
+    // per gather slot i: levels 4i..4i+3: 1 = all dense, 2 = all hashed, 0 = mixed, 3 = all dense and none of them can
+    // wrap (hash_level MODE 3: the x-corner pairs as one load).  A dense index is gx + gy * res + gz * res^2 with every
+    // g <= floor(scale + 0.5) + 1 (positions are clamped to [0, 1]); when that bound stays below the level's size the
+    // reference's `% size` never acts and entry idx + 1 is the +x neighbour of entry idx.
     A.level_mode = 0;
     for (int i = 0; i < 4; ++i) {
         int n_hashed = 0;
-        for (int g = 0; g < 4; ++g) n_hashed += d->hash.hashed[4 * i + g] ? 1 : 0;
-        A.level_mode |= (n_hashed == 0 ? 1 : (n_hashed == 4 ? 2 : 0)) << (2 * i);
+        bool no_wrap = !A.temporal;
+        for (int g = 0; g < 4; ++g) {
+            const int l = 4 * i + g;
+            n_hashed += d->hash.hashed[l] ? 1 : 0;
+            const uint64_t gmax = (uint64_t)(d->hash.scale[l] + 0.5f) + 1u, res = d->hash.res[l];
+            no_wrap = no_wrap && l < d->hash.n_levels && gmax * (1u + res + res * res) < (uint64_t)d->hash.size[l];
+        }
+        A.level_mode |= (n_hashed == 0 ? (no_wrap ? 3 : 1) : (n_hashed == 4 ? 2 : 0)) << (2 * i);
     }
     // byte offsets are 32-bit
     CED_REQUIRE(d->hash.total_entries * (uint64_t)((A.table_dtype ? 4 : 8) * (A.temporal ? 4 : 1)) < (1ull << 32),
@@ -413,10 +422,11 @@ int launch_field(const ced_field_desc *d, FieldArgs &A, void *stream)
         // the half kernels gather level 4i + g in slot i: the same slot -> level-range mapping as above
         return launch_field_half(A, d->time_mode, d->mlp_precision, stream);
     }
-    // 768 threads (three waves per SIMD, 168 registers) is the default; the time-embedding and temporal-table kernels
-    // spill at that cap (76-380 B per lane) and run two waves per SIMD without scratch instead (C3: +1.8 %)
+    // 1024 threads (four waves per SIMD, 128 registers) is the default since the dense levels' pair loads of round 4 (the
+    // kernels fit without scratch: C2 +2.4 %, C3 +2 % over 768 threads); the temporal-table kernels need 250-300 registers
+    // and run two waves per SIMD without scratch instead.
     const int field_variant = g_field_variant.load(std::memory_order_relaxed);
-    const int variant = (field_variant == 2 && (d->time_mode || A.temporal)) ? 1 : field_variant;
+    const int variant = (field_variant >= 2 && field_variant <= 3 && A.temporal) ? 1 : field_variant;
     auto launch = [&](auto kernel, int nt, int threads) {
         const int64_t n_tiles = (A.n + 16 * nt - 1) / (16 * nt);
         const int waves = threads / 64;
@@ -473,7 +483,7 @@ extern "C" int ced_set_option(const char *key, int value)
         return CED_OK;
     }
     if (strcmp(key, "half_variant") == 0) {
-        CED_REQUIRE(value >= 0 && value <= 3, "set_option: half_variant must be 0..2 (3: diagnostic builds only)");
+        CED_REQUIRE(value >= 0 && value <= 4, "set_option: half_variant must be 0..3 (4: diagnostic builds only)");
         ced::set_half_variant(value);
         return CED_OK;
     }

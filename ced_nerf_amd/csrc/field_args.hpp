@@ -28,7 +28,7 @@ struct FieldArgs {
     int table_dtype, temporal;
     int stagger;                                      // start-up phase offset between SIMD-mates (s_sleep(127) units)
     int spread_tiles;                                 // tile -> wave mapping (field.hip); ced_set_option("field_spread_tiles")
-    int level_mode;                                   // 2 bits per gather slot: 0 mixed, 1 all dense, 2 all hashed
+    int level_mode;                                   // 2 bits per gather slot: 0 mixed, 1 all dense, 2 all hashed, 3 all dense and cannot wrap
     int max_blocks;                                   // workgroups of the launch (ced_field_desc.max_workgroups; <= 0: one per CU)
     const void *table;
     float scale[CED_MAX_LEVELS];

@@ -104,7 +104,8 @@ __device__ __forceinline__ LevelConst load_level(const uint32_t *lt)
 
 // Trilinear gather of one level for one point (hash_encoder_half.py:112-161; temporal variant
 // hash_encoder_inter.py:148-197).  x already clamped to [0,1].  MODE: 0 = this lane's level may be
-// dense or hashed (both index forms computed, selected per lane), 1 = dense, 2 = hashed.
+// dense or hashed (both index forms computed, selected per lane), 1 = dense, 2 = hashed, 3 = dense and known not to wrap
+// (non-temporal tables: the x-corner pairs are fetched with one load each).
 template <bool F16, bool TEMPORAL, int MODE>
 __device__ __forceinline__ void hash_level(const LevelConst &L, const void *__restrict__ table, const float (&x)[3],
                                            int k_lo, float t_frac, float &f0, float &f1)
@@ -129,8 +130,8 @@ __device__ __forceinline__ void hash_level(const LevelConst &L, const void *__re
     // their products are single full-rate 24-bit multiplies; hashed levels need the 32-bit wrap-around product
     constexpr uint32_t EB = EntryBytes<F16, TEMPORAL>::value;
     const uint32_t x0 = g[0] * EB;
-    const uint32_t y0 = (MODE == 1) ? __umul24(g[1], L.syb) : g[1] * L.syb;
-    const uint32_t z0 = (MODE == 1) ? __umul24(g[2], L.szb) : g[2] * L.szb;
+    const uint32_t y0 = (MODE == 1 || MODE == 3) ? __umul24(g[1], L.syb) : g[1] * L.syb;
+    const uint32_t z0 = (MODE == 1 || MODE == 3) ? __umul24(g[2], L.szb) : g[2] * L.szb;
     const uint32_t xs[2] = { x0, x0 + EB };
     const uint32_t ys[2] = { y0, y0 + L.syb };
     const uint32_t zs[2] = { z0, z0 + L.szb };
@@ -139,7 +140,7 @@ __device__ __forceinline__ void hash_level(const LevelConst &L, const void *__re
     uint32_t yz_x[4], yz_a[4];
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
-        if constexpr (MODE != 1) yz_x[q] = ys[q & 1] ^ zs[q >> 1];
+        if constexpr (MODE != 1 && MODE != 3) yz_x[q] = ys[q & 1] ^ zs[q >> 1];
         if constexpr (MODE != 2) yz_a[q] = ys[q & 1] + zs[q >> 1];
     }
     const float wxy[4] = { om[0] * om[1], fr[0] * om[1], om[0] * fr[1], fr[0] * fr[1] };   // index cx + 2*cy
@@ -149,14 +150,14 @@ __device__ __forceinline__ void hash_level(const LevelConst &L, const void *__re
     for (int c = 0; c < 8; ++c) {
         const int cx = c & 1, cy = (c >> 1) & 1, cz = (c >> 2) & 1;
         uint32_t hb = 0, db = 0;
-        if constexpr (MODE != 1) hb = (xs[cx] ^ yz_x[cy + 2 * cz]) & L.maskb;
+        if constexpr (MODE != 1 && MODE != 3) hb = (xs[cx] ^ yz_x[cy + 2 * cz]) & L.maskb;
         if constexpr (MODE != 2) {
             // idx % size with idx < 2 * size: the unsigned difference wraps to a huge value when idx < size
             const uint32_t dx = xs[cx] + yz_a[cy + 2 * cz];
             const uint32_t dw = dx - L.sizeb;
             db = dx < dw ? dx : dw;
         }
-        const uint32_t idxb = (MODE == 1) ? db : (MODE == 2) ? hb : (hashed ? hb : db);
+        const uint32_t idxb = (MODE == 1 || MODE == 3) ? db : (MODE == 2) ? hb : (hashed ? hb : db);
 #ifdef CED_AB_GATHER_WINDOW            // diagnostic builds (tools/ab_build.sh): the gathers of a level confined to a byte window
         off[c] = L.offb + (idxb & (uint32_t)(CED_AB_GATHER_WINDOW));
 #else
@@ -169,7 +170,23 @@ __device__ __forceinline__ void hash_level(const LevelConst &L, const void *__re
     // (v_pk_fma_f32 is the same IEEE fma per component as two scalar ones)
     f2 v[8];
     if constexpr (!TEMPORAL) {
-        if constexpr (!F16) {
+        if constexpr (MODE == 3) {
+            // dense level whose indices cannot wrap (decided on the host, field.hip): the two x corners of a (y, z) corner
+            // are adjacent entries -- ONE 16-byte (fp16 table: 8-byte) load instead of two on the same cache line
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                if constexpr (!F16) {
+                    const f4 pr = *reinterpret_cast<const f4 *>(tb + off[2 * q]);
+                    v[2 * q] = f2{ pr[0], pr[1] };
+                    v[2 * q + 1] = f2{ pr[2], pr[3] };
+                } else {
+                    typedef uint32_t u2v __attribute__((ext_vector_type(2)));
+                    const u2v u = *reinterpret_cast<const u2v *>(tb + off[2 * q]);
+                    v[2 * q] = f2{ half_bits_to_float((uint16_t)(u[0] & 0xffffu)), half_bits_to_float((uint16_t)(u[0] >> 16)) };
+                    v[2 * q + 1] = f2{ half_bits_to_float((uint16_t)(u[1] & 0xffffu)), half_bits_to_float((uint16_t)(u[1] >> 16)) };
+                }
+            }
+        } else if constexpr (!F16) {
 #pragma unroll
             for (int c = 0; c < 8; ++c) v[c] = *reinterpret_cast<const f2 *>(tb + off[c]);
         } else {

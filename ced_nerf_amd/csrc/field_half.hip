@@ -211,6 +211,10 @@ __global__ __launch_bounds__(THREADS) void field_half_kernel(FieldArgs A)
 #pragma unroll
                 for (int j = 0; j < NT; ++j)
                     hash_level<F16, TEMPORAL, 2>(L, A.table, xn[j], k_lo[j], t_frac[j], R[j][2 * i], R[j][2 * i + 1]);
+            } else if (mode == 3) {
+#pragma unroll
+                for (int j = 0; j < NT; ++j)
+                    hash_level<F16, TEMPORAL, 3>(L, A.table, xn[j], k_lo[j], t_frac[j], R[j][2 * i], R[j][2 * i + 1]);
             } else {
 #pragma unroll
                 for (int j = 0; j < NT; ++j)
@@ -351,17 +355,25 @@ int launch_field_half(FieldArgs &A, int time_mode, int precision, void *stream)
     case 6: launch(field_half_kernel<false, true, true, SP_, NT_, TH_>, NT_, TH_); break;                       \
     default: launch(field_half_kernel<true, true, true, SP_, NT_, TH_>, NT_, TH_); break;                       \
     }
-    // 768 threads (three waves per SIMD, 168 registers) is the default; the time-embedding and temporal-table kernels
-    // spill at that cap (16-100 registers) and run two waves per SIMD without scratch instead (C3 +1.7 %, C4 +4 %), as
-    // the fp32 kernels do (field.hip)
+    // Launch geometry ("half_variant": 0 = automatic, 1 = 2 x 512, 2 = 2 x 1024, 3 = 2 x 768 threads; env CED_HALF_AUTO_*
+    // override the automatic picks for A/B runs).  Which kernels fit which register cap without scratch is printed by
+    // tools/kernel_schedule.py; the automatic rule follows the round-4 measurements (profiles/r04_ab_half_geometry.txt).
+    static const int auto_plain_split = [] { const char *e = getenv("CED_HALF_AUTO_F16X2"); return e ? atoi(e) : 2; }();
+    static const int auto_plain = [] { const char *e = getenv("CED_HALF_AUTO_F16"); return e ? atoi(e) : 3; }();
+    static const int auto_te = [] { const char *e = getenv("CED_HALF_AUTO_TE"); return e ? atoi(e) : 3; }();
     const int requested_variant = g_half_variant.load(std::memory_order_relaxed);
-    const int half_variant = (requested_variant == 0 && (time_mode || A.temporal)) ? 1 : requested_variant;
+    int half_variant = requested_variant;
+    if (half_variant == 0) {
+        if (A.temporal) half_variant = 1;                    // temporal tables: 228-248 registers, scratch above 512 threads
+        else if (time_mode) half_variant = auto_te;
+        else half_variant = precision == CED_MLP_F16X2 ? auto_plain_split : auto_plain;
+    }
     if (precision == CED_MLP_F16X2) {
         switch (half_variant) {
         case 1: CED_HALF_CASE(true, 2, 512) break;
         case 2: CED_HALF_CASE(true, 2, 1024) break;
 #ifdef CED_AB_HALF_NT1
-        case 3: CED_HALF_CASE(true, 1, 1024) break;
+        case 4: CED_HALF_CASE(true, 1, 1024) break;
 #endif
         default: CED_HALF_CASE(true, 2, 768) break;
         }
@@ -370,7 +382,7 @@ int launch_field_half(FieldArgs &A, int time_mode, int precision, void *stream)
         case 1: CED_HALF_CASE(false, 2, 512) break;
         case 2: CED_HALF_CASE(false, 2, 1024) break;
 #ifdef CED_AB_HALF_NT1
-        case 3: CED_HALF_CASE(false, 1, 1024) break;
+        case 4: CED_HALF_CASE(false, 1, 1024) break;
 #endif
         default: CED_HALF_CASE(false, 2, 768) break;
         }

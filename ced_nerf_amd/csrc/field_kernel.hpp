@@ -334,6 +334,10 @@ __global__ __launch_bounds__(THREADS) void field_kernel(FieldArgs A)
 #pragma unroll
                 for (int j = 0; j < NT; ++j)
                     hash_level<F16, TEMPORAL, 2>(L, A.table, xn[j], k_lo[j], t_frac[j], R[j][2 * i], R[j][2 * i + 1]);
+            } else if (mode == 3) {
+#pragma unroll
+                for (int j = 0; j < NT; ++j)
+                    hash_level<F16, TEMPORAL, 3>(L, A.table, xn[j], k_lo[j], t_frac[j], R[j][2 * i], R[j][2 * i + 1]);
             } else {
 #pragma unroll
                 for (int j = 0; j < NT; ++j)

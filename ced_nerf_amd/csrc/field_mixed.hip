@@ -22,8 +22,8 @@
 
 namespace ced {
 
-// launch geometry (ced_set_option("mixed_variant")): 0 = 768 threads, 512 for the time-embedding / temporal-table
-// kernels (which spill at three waves per SIMD); 1 = 512; 2 = 768
+// launch geometry (ced_set_option("mixed_variant")): 0 = 768 threads, 512 for the temporal-table kernels (which spill at
+// three waves per SIMD); 1 = 512; 2 = 768
 static std::atomic<int> g_mixed_variant{ [] { const char *e = getenv("CED_MIXED_VARIANT"); return e ? atoi(e) : 0; }() };
 void set_mixed_variant(int v) { g_mixed_variant = v; }
 
@@ -38,9 +38,9 @@ int launch_field_mixed(FieldArgs &A, int time_mode, void *stream)
         hipLaunchKernelGGL(kernel, dim3((unsigned)blocks), dim3(threads), 0, (hipStream_t)stream, A);
     };
     const int sel = (time_mode ? 1 : 0) | (A.table_dtype ? 2 : 0) | (A.temporal ? 4 : 0);
-    // 768 threads (three waves per SIMD); the time-embedding and temporal-table kernels run 512 (see field.hip)
+    // 768 threads (three waves per SIMD); the temporal-table kernels run 512 (see field.hip)
     const int mv = g_mixed_variant.load(std::memory_order_relaxed);
-    const bool small = mv == 1 || (mv == 0 && (time_mode || A.temporal));
+    const bool small = mv == 1 || (mv == 0 && A.temporal);
 #define CED_MIXED_CASE(TH_)                                                                                    \
     switch (sel) {                                                                                              \
     case 0: launch(field_kernel<false, false, false, 2, TH_, true>, 2, TH_); break;                             \

@@ -77,9 +77,10 @@ const char *ced_last_error_string(void);
 
 /* Diagnostic knobs (process-wide; results are identical for every setting -- launch properties that callers vary
  * per call, such as the workgroup count of a field launch, are descriptor fields instead).  "field_variant": launch geometry of the fused field kernel,
- * 0 = 4 column tiles x 512 threads, 1 = 2 x 512, 2 = 2 x 768 (default), 3 = 2 x 1024, 4 = 1 x 1024;
- * "half_variant": the same for the half-precision kernels, 0 = automatic (default: 2 x 768; 2 x 512 for the time-embedding
- * and temporal-table kernels, which spill at 768), 1 = 2 x 512, 2 = 2 x 1024;
+ * 0 = 4 column tiles x 512 threads, 1 = 2 x 512, 2 = 2 x 768, 3 = 2 x 1024 (default; the temporal-table kernels, which need
+ * more registers, take 2 x 512), 4 = 1 x 1024;
+ * "half_variant": the same for the half-precision kernels, 0 = automatic (default: f16x2 2 x 1024, f16 and the
+ * time-embedding kernels 2 x 768, temporal tables 2 x 512), 1 = 2 x 512, 2 = 2 x 1024, 3 = 2 x 768;
  * "field_spread_tiles": 1 deals the sample tiles of a launch across all CUs in groups of four before any CU takes
  * more (shorter last round, lower frame latency); 2 (default) does the same inside each XCD, the eight XCDs taking eight
  * contiguous parts of the sample stream (one L2 per table line instead of up to eight); 0 = contiguous tiles per workgroup;
