@@ -394,21 +394,20 @@ int launch_field(const ced_field_desc *d, FieldArgs &A, void *stream)
         A.size[l] = d->hash.size[l];
         A.hashed[l] = d->hash.hashed[l];
     }
-    // per gather slot i: levels 4i..4i+3: 1 = all dense, 2 = all hashed, 0 = mixed, 3 = all dense and none of them can
-    // wrap (hash_level MODE 3: the x-corner pairs as one load).  A dense index is gx + gy * res + gz * res^2 with every
-    // g <= floor(scale + 0.5) + 1 (positions are clamped to [0, 1]); when that bound stays below the level's size the
-    // reference's `% size` never acts and entry idx + 1 is the +x neighbour of entry idx.
+    // per gather slot i: levels 4i..4i+3: 1 = all dense, 2 = all hashed, 0 = mixed, 3 = all dense with the x-corner pairs
+    // as one load (hash_level MODE 3): non-temporal tables, and every level of the slot followed by another level of the
+    // table -- the pair load of a level's last entry reads one entry past the level.
     A.level_mode = 0;
     for (int i = 0; i < 4; ++i) {
         int n_hashed = 0;
-        bool no_wrap = !A.temporal;
+        bool pairs = !A.temporal;
         for (int g = 0; g < 4; ++g) {
             const int l = 4 * i + g;
             n_hashed += d->hash.hashed[l] ? 1 : 0;
-            const uint64_t gmax = (uint64_t)(d->hash.scale[l] + 0.5f) + 1u, res = d->hash.res[l];
-            no_wrap = no_wrap && l < d->hash.n_levels && gmax * (1u + res + res * res) < (uint64_t)d->hash.size[l];
+            pairs = pairs && l + 1 < d->hash.n_levels &&
+                    (uint64_t)d->hash.offset[l] + d->hash.size[l] < d->hash.total_entries;
         }
-        A.level_mode |= (n_hashed == 0 ? (no_wrap ? 3 : 1) : (n_hashed == 4 ? 2 : 0)) << (2 * i);
+        A.level_mode |= (n_hashed == 0 ? (pairs ? 3 : 1) : (n_hashed == 4 ? 2 : 0)) << (2 * i);
     }
     // byte offsets are 32-bit
     CED_REQUIRE(d->hash.total_entries * (uint64_t)((A.table_dtype ? 4 : 8) * (A.temporal ? 4 : 1)) < (1ull << 32),

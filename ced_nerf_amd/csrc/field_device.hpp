@@ -104,8 +104,8 @@ __device__ __forceinline__ LevelConst load_level(const uint32_t *lt)
 
 // Trilinear gather of one level for one point (hash_encoder_half.py:112-161; temporal variant
 // hash_encoder_inter.py:148-197).  x already clamped to [0,1].  MODE: 0 = this lane's level may be
-// dense or hashed (both index forms computed, selected per lane), 1 = dense, 2 = hashed, 3 = dense and known not to wrap
-// (non-temporal tables: the x-corner pairs are fetched with one load each).
+// dense or hashed (both index forms computed, selected per lane), 1 = dense, 2 = hashed, 3 = dense with the x-corner
+// pairs fetched by one load each (non-temporal tables, levels followed by another level).
 template <bool F16, bool TEMPORAL, int MODE>
 __device__ __forceinline__ void hash_level(const LevelConst &L, const void *__restrict__ table, const float (&x)[3],
                                            int k_lo, float t_frac, float &f0, float &f1)
@@ -171,19 +171,24 @@ __device__ __forceinline__ void hash_level(const LevelConst &L, const void *__re
     f2 v[8];
     if constexpr (!TEMPORAL) {
         if constexpr (MODE == 3) {
-            // dense level whose indices cannot wrap (decided on the host, field.hip): the two x corners of a (y, z) corner
-            // are adjacent entries -- ONE 16-byte (fp16 table: 8-byte) load instead of two on the same cache line
+            // dense level (not the table's last: field.hip): the two x corners of a (y, z) corner are adjacent entries -- ONE
+            // 16-byte (fp16 table: 8-byte) load instead of two on the same cache line.  The one exception is the reference's
+            // `% size` acting between the two (the +x corner is the level's entry 0): that lane re-reads its second corner.
+            constexpr uint32_t EBp = EntryBytes<F16, TEMPORAL>::value;
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
                 if constexpr (!F16) {
                     const f4 pr = *reinterpret_cast<const f4 *>(tb + off[2 * q]);
                     v[2 * q] = f2{ pr[0], pr[1] };
                     v[2 * q + 1] = f2{ pr[2], pr[3] };
+                    if (off[2 * q + 1] != off[2 * q] + EBp) v[2 * q + 1] = *reinterpret_cast<const f2 *>(tb + off[2 * q + 1]);
                 } else {
                     typedef uint32_t u2v __attribute__((ext_vector_type(2)));
                     const u2v u = *reinterpret_cast<const u2v *>(tb + off[2 * q]);
+                    uint32_t u1 = u[1];
+                    if (off[2 * q + 1] != off[2 * q] + EBp) u1 = *reinterpret_cast<const uint32_t *>(tb + off[2 * q + 1]);
                     v[2 * q] = f2{ half_bits_to_float((uint16_t)(u[0] & 0xffffu)), half_bits_to_float((uint16_t)(u[0] >> 16)) };
-                    v[2 * q + 1] = f2{ half_bits_to_float((uint16_t)(u[1] & 0xffffu)), half_bits_to_float((uint16_t)(u[1] >> 16)) };
+                    v[2 * q + 1] = f2{ half_bits_to_float((uint16_t)(u1 & 0xffffu)), half_bits_to_float((uint16_t)(u1 >> 16)) };
                 }
             }
         } else if constexpr (!F16) {
