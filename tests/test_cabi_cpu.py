@@ -372,6 +372,52 @@ def test_built_library_has_no_src1_high_op_sel_packed_fp32():
     assert not bad, f"kernels with a src1-high op_sel packed-fp32 instruction: {sorted(bad)}"
 
 
+def test_default_field_kernels_fit_their_launch_geometry():
+    """The automatic launch geometry of the field kernels (field.hip / field_half.hip: workgroup size per arithmetic and
+    table kind) is chosen so that the kernel runs WITHOUT scratch at that many waves per SIMD.  hipcc's register allocation
+    of these kernels is sensitive to their code shape (round 4: 168 registers + scratch became 107-145 after an unrelated
+    edit), so the built code objects are checked: kernel (template arguments) -> registers allowed, spilt registers allowed."""
+    import importlib.util
+    import re
+    import shutil
+    import subprocess
+    import tempfile
+    from ced_nerf_amd import _lib
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    spec = importlib.util.spec_from_file_location("isa_lint", os.path.join(root, "tools", "isa_lint.py"))
+    lint = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(lint)
+    readelf = os.path.join(os.path.dirname(lint.OBJDUMP), "llvm-readelf")
+    if not (os.path.exists(readelf) or shutil.which(readelf)):
+        pytest.skip("llvm-readelf not found")
+    stats = {}
+    for image in lint.code_objects(_lib.build()):
+        with tempfile.NamedTemporaryFile(suffix=".co") as f:
+            f.write(image)
+            f.flush()
+            notes = subprocess.run([readelf, "--notes", f.name], capture_output=True, text=True, check=True).stdout
+        for blk in notes.split("- .agpr_count")[1:]:
+            name = re.search(r"\.name:\s+(\S+)", blk).group(1)
+            stats[name] = (int(re.search(r"\.vgpr_count:\s+(\d+)", blk).group(1)),
+                           int(re.search(r"\.vgpr_spill_count:\s+(\d+)", blk).group(1)))
+    half = "_ZN3ced17field_half_kernelILb{te}ELb{f16}ELb{temporal}ELb{split}ELi2ELi{threads}EEEvNS_9FieldArgsE"
+    f32 = "_ZN3ced12field_kernelILb{te}ELb{f16}ELb{temporal}ELi2ELi{threads}ELb{head16}EEEvNS_9FieldArgsE"
+    want = []
+    for f16 in (0, 1):
+        want += [(half.format(te=0, f16=f16, temporal=0, split=1, threads=1024), 128, 0),      # f16x2: four waves per SIMD
+                 (half.format(te=0, f16=f16, temporal=0, split=0, threads=768), 168, 0),       # f16: three
+                 (half.format(te=1, f16=f16, temporal=0, split=1, threads=768), 168, 0),       # time embedding: three
+                 (half.format(te=1, f16=f16, temporal=0, split=0, threads=768), 168, 0),
+                 (f32.format(te=0, f16=f16, temporal=0, threads=1024, head16=0), 128, 8),      # fp32: four
+                 (f32.format(te=0, f16=f16, temporal=0, threads=768, head16=1), 168, 0)]       # mixed: three
+        for te in (0, 1):                                                                      # temporal tables: two
+            want += [(half.format(te=te, f16=f16, temporal=1, split=1, threads=512), 256, 2),
+                     (f32.format(te=te, f16=f16, temporal=1, threads=512, head16=0), 256, 2)]
+    for name, regs, spills in want:
+        assert name in stats, f"{name} not in the built library"
+        assert stats[name][0] <= regs and stats[name][1] <= spills, f"{name}: {stats[name][0]} registers, {stats[name][1]} spilt"
+
+
 def test_reference_checkpoint_layout_round_trip_cpu(tmp_path):
     """f3 (train_real.py:433-441,524-529), tiny-cuda-nn half: a `model.pth` written in the documented layout hypothesis
     (tools/write_reference_checkpoint.py: flat `params` per tcnn module, 16-padded row-major matrices, ones-padded inputs)
