@@ -208,15 +208,17 @@ __device__ __forceinline__ void hash_level(const LevelConst &L, const void *__re
         if constexpr (!F16) {
 #pragma unroll
             for (int c = 0; c < 8; ++c) {
-                const f2 lo = *reinterpret_cast<const f2 *>(tb + off[c] + kb);
-                const f2 hi = *reinterpret_cast<const f2 *>(tb + off[c] + kb + 8u);
+                // key-frames k and k + 1 of an entry are adjacent: ONE 16-byte load (rounds 1-4: two 8-byte loads)
+                const f4 pr = *reinterpret_cast<const f4 *>(tb + off[c] + kb);
+                const f2 lo = { pr[0], pr[1] }, hi = { pr[2], pr[3] };
                 v[c] = lo * omt2 + hi * tf2;
             }
         } else {
 #pragma unroll
             for (int c = 0; c < 8; ++c) {
-                const uint32_t lo = *reinterpret_cast<const uint32_t *>(tb + off[c] + kb);
-                const uint32_t hi = *reinterpret_cast<const uint32_t *>(tb + off[c] + kb + 4u);
+                typedef uint32_t u2t __attribute__((ext_vector_type(2)));
+                const u2t pr = *reinterpret_cast<const u2t *>(tb + off[c] + kb);
+                const uint32_t lo = pr[0], hi = pr[1];
                 const f2 a = { half_bits_to_float((uint16_t)(lo & 0xffffu)), half_bits_to_float((uint16_t)(lo >> 16)) };
                 const f2 b = { half_bits_to_float((uint16_t)(hi & 0xffffu)), half_bits_to_float((uint16_t)(hi >> 16)) };
                 v[c] = a * omt2 + b * tf2;
